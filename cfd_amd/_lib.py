@@ -1,0 +1,136 @@
+"""ctypes binding of libcfd_hip.so (include/cfd_hip.h).
+
+The HIP extension is the product path: if the shared library is missing or a GPU call
+fails, this module raises -- there is no CPU fallback anywhere in cfd_amd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("CFD_HIP_LIB", _HERE / "libcfd_hip.so"))
+
+F_U, F_V, F_P, F_K, F_OMEGA, F_NUT, F_PCORR, F_AP, F_AI, F_AJ, F_BU, F_BV = range(12)
+KIND_GHOSTED, KIND_CELL, KIND_FACE_I, KIND_FACE_J = range(4)
+SIDE_IMIN, SIDE_IMAX, SIDE_JMIN, SIDE_JMAX = range(4)
+SIDES = {"i_min": 0, "i_max": 1, "j_min": 2, "j_max": 3}
+BC_NONE, BC_AFFINE, BC_SYMMETRY, BC_PERIODIC = range(4)
+TOP_WRAP_I, TOP_WRAP_J, TOP_SET_INTERIOR, TOP_AFFINE_GHOST = range(4)
+FIELD_IDS = {"u": F_U, "v": F_V, "p": F_P, "k": F_K, "omega": F_OMEGA, "nu_t": F_NUT, "p_corr": F_PCORR}
+
+
+class TurbOp(C.Structure):
+    _fields_ = [("op", C.c_int32), ("field", C.c_int32), ("side", C.c_int32), ("lo", C.c_int32),
+                ("hi", C.c_int32), ("value_off", C.c_int32), ("a", C.c_double)]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [("mom_iters", C.c_int32), ("p_iters", C.c_int32), ("k_iters", C.c_int32),
+                ("p_solver", C.c_int32), ("mom_relres", C.c_double * 2), ("p_relres", C.c_double),
+                ("k_relres", C.c_double * 2)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/cfd_hip.h declares
+SIGNATURES = {
+    "cfd_last_error": (C.c_char_p, []),
+    "cfd_version": (C.c_int, []),
+    "cfd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "cfd_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]),
+    "cfd_destroy": (C.c_int, [_vp]),
+    "cfd_set_stream": (C.c_int, [_vp, _vp]),
+    "cfd_synchronize": (C.c_int, [_vp]),
+    "cfd_pitch": (C.c_int, [_vp]),
+    "cfd_field_offset": (C.c_int64, [_vp, C.c_int]),
+    "cfd_upload_mesh": (C.c_int, [_vp] + [_dp] * 9),
+    "cfd_mesh_from_nodes": (C.c_int, [_vp, _dp]),
+    "cfd_mesh_from_rect": (C.c_int, [_vp, _dp, _dp]),
+    "cfd_download_mesh_plane": (C.c_int, [_vp, C.c_int, _dp]),
+    "cfd_upload_field": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    "cfd_download_field": (C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    "cfd_set_physics": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]),
+    "cfd_set_solver": (C.c_int, [_vp, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]),
+    "cfd_set_multigrid": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
+    "cfd_set_turbulence_clip": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "cfd_set_flow_bc": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip] + [_dp] * 8),
+    "cfd_set_periodicity": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cfd_set_pressure_bc": (C.c_int, [_vp, _ip, _ip, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "cfd_set_turb_bc": (C.c_int, [_vp, C.c_int, C.POINTER(TurbOp), C.c_int, _dp]),
+    "cfd_apply_flow_bc": (C.c_int, [_vp]),
+    "cfd_compute_dt": (C.c_int, [_vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double, _dp]),
+    "cfd_simple_iter": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, _dp]),
+    "cfd_piso_step": (C.c_int, [_vp, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, _dp]),
+    "cfd_turbulence_step": (C.c_int, [_vp, C.c_double]),
+    "cfd_get_stats": (C.c_int, [_vp, C.POINTER(SolveStats)]),
+    "cfd_bulk_velocity": (C.c_int, [_vp, C.c_int, _dp]),
+    "cfd_eddy_viscosity": (C.c_int, [_vp]),
+    "cfd_momentum_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),
+    "cfd_face_flux": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
+    "cfd_grad": (C.c_int, [_vp, C.c_int, _dp]),
+    "cfd_advect": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "cfd_momentum_rhs": (C.c_int, [_vp, C.c_double]),
+    "cfd_momentum_solve": (C.c_int, [_vp, _dp]),
+    "cfd_pressure_solve": (C.c_int, [_vp]),
+    "cfd_download_pressure_system": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "cfd_correct": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
+    "cfd_snapshot": (C.c_int, [_vp]),
+    "cfd_continuity": (C.c_int, [_vp, _dp]),
+    "cfd_apply_turb_bc": (C.c_int, [_vp]),
+    "cfd_spmv": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "cfd_vcycle": (C.c_int, [_vp, _dp, _dp]),
+    "cfd_pressure_krylov": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_int, C.POINTER(C.c_int), _dp]),
+    "cfd_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "cfd_phase_times": (C.c_int, [_vp, _dp, C.c_int]),
+    "cfd_enable_phase_timing": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libcfd_hip.so; raises HipError if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise HipError(f"HIP extension not built: {LIB_PATH} is missing. Run "
+                       f"`python -c 'import __graft_entry__ as g; g.build()'` (make -C cfd_amd/csrc).")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cfd_last_error().decode("utf-8", "replace")
+        raise HipError(f"libcfd_hip error {rc}: {msg}")
+
+
+def dptr(a):
+    """double* of a C-contiguous float64 array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], "need C-contiguous float64"
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    if a is None:
+        return None
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_ip)

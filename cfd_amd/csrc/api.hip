@@ -1,0 +1,846 @@
+// C ABI of libcfd_hip.so (see include/cfd_hip.h): context, host<->device layout
+// conversion, and the sequencing of one SIMPLE iteration / PISO step / k-omega step.
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+
+#include "internal.h"
+
+namespace cfd {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------ layout conversion
+// host array [a][b][comp] (C order, b fastest but for comp) <-> device plane(s) [jg][ig].
+// 32x32 LDS tile so that both the host-side and the plane-side accesses are coalesced.
+template <bool TO_DEVICE>
+__global__ void k_transpose(Geo g, int n0, int n1, int ncomp, int comp, int off, double *stage, double *plane) {
+    __shared__ double tile[32][33];
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    if (TO_DEVICE) {
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int a = a0 + r, b = b0 + threadIdx.x;
+            if (a < n0 && b < n1) tile[r][threadIdx.x] = stage[((size_t)a * n1 + b) * ncomp + comp];
+        }
+        __syncthreads();
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int b = b0 + r, a = a0 + threadIdx.x;
+            if (a < n0 && b < n1) plane[g.at(a + off, b + off)] = tile[threadIdx.x][r];
+        }
+    } else {
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int b = b0 + r, a = a0 + threadIdx.x;
+            if (a < n0 && b < n1) tile[threadIdx.x][r] = plane[g.at(a + off, b + off)];
+        }
+        __syncthreads();
+        for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+            const int a = a0 + r, b = b0 + threadIdx.x;
+            if (a < n0 && b < n1) stage[((size_t)a * n1 + b) * ncomp + comp] = tile[r][threadIdx.x];
+        }
+    }
+}
+
+static void kind_shape(const Geo &g, int kind, int &n0, int &n1, int &off) {
+    switch (kind) {
+        case CFD_KIND_CELL_GHOSTED: n0 = g.ni + 2; n1 = g.nj + 2; off = 0; break;
+        case CFD_KIND_CELL: n0 = g.ni; n1 = g.nj; off = 1; break;
+        case CFD_KIND_FACE_I: n0 = g.ni + 1; n1 = g.nj; off = 1; break;
+        default: n0 = g.ni; n1 = g.nj + 1; off = 1; break;
+    }
+}
+
+static int to_device_comp(Ctx *c, const double *host, int ncomp, double *const planes[], int kind) {
+    int n0, n1, off;
+    kind_shape(c->g, kind, n0, n1, off);
+    const size_t bytes = (size_t)n0 * n1 * ncomp * sizeof(double);
+    CFD_HIP(hipMemcpyAsync(c->stage_a, host, bytes, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((n1 + 31) / 32, (n0 + 31) / 32), blk(32, 8);
+    for (int q = 0; q < ncomp; ++q)
+        hipLaunchKernelGGL((k_transpose<true>), grid, blk, 0, c->stream, c->g, n0, n1, ncomp, q, off, c->stage_a, planes[q]);
+    CFD_HIP(hipGetLastError());
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+static int from_device_comp(Ctx *c, double *const planes[], int ncomp, double *host, int kind) {
+    int n0, n1, off;
+    kind_shape(c->g, kind, n0, n1, off);
+    const size_t bytes = (size_t)n0 * n1 * ncomp * sizeof(double);
+    const dim3 grid((n1 + 31) / 32, (n0 + 31) / 32), blk(32, 8);
+    for (int q = 0; q < ncomp; ++q)
+        hipLaunchKernelGGL((k_transpose<false>), grid, blk, 0, c->stream, c->g, n0, n1, ncomp, q, off, c->stage_a, planes[q]);
+    CFD_HIP(hipGetLastError());
+    CFD_HIP(hipMemcpyAsync(host, c->stage_a, bytes, hipMemcpyDeviceToHost, c->stream));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+int to_device(Ctx *c, const double *host, double *plane, int kind) {
+    double *pl[1] = {plane};
+    return to_device_comp(c, host, 1, pl, kind);
+}
+int from_device(Ctx *c, const double *plane, double *host, int kind) {
+    double *pl[1] = {const_cast<double *>(plane)};
+    return from_device_comp(c, pl, 1, host, kind);
+}
+
+// ------------------------------------------------------------------ workspace layout
+static std::vector<Geo> level_geometry(int ni, int nj) {
+    std::vector<Geo> out;
+    Geo g{ni, nj, pitch_for(ni)};
+    out.push_back(g);
+    const int mg_min = 4;
+    while ((int)out.size() < MAX_LEVELS) {
+        const Geo &f = out.back();
+        const int ci = f.ni > mg_min ? (f.ni + 1) / 2 : f.ni;
+        const int cj = f.nj > mg_min ? (f.nj + 1) / 2 : f.nj;
+        if (ci == f.ni && cj == f.nj) break;
+        out.push_back(Geo{ci, cj, pitch_for(ci)});
+    }
+    return out;
+}
+
+static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+constexpr int N_FINE_PLANES = 12 + 6 + 3 + 4 + 3 + 3 + 2 + 2 + 16 + 3;
+constexpr size_t MISC_BYTES = (size_t)4 * MAX_PARTIALS * sizeof(double) + 4096;
+
+static size_t workspace_bytes_impl(int ni, int nj, size_t bc_bytes) {
+    const std::vector<Geo> lv = level_geometry(ni, nj);
+    size_t total = (size_t)N_FINE_PLANES * align256(lv[0].plane_elems() * sizeof(double));
+    for (size_t l = 1; l < lv.size(); ++l) total += 6 * align256(lv[l].plane_elems() * sizeof(double));
+    total += MISC_BYTES + bc_bytes + 4096;
+    return total;
+}
+
+static size_t bc_bytes_for(int ni, int nj) {
+    const size_t n = (size_t)(ni > nj ? ni : nj);
+    // per side: 2 int32 + 8 doubles per index; pressure masks 4 x int32; turbulence values 16 doubles per index
+    return 4 * align256(n * (2 * 4 + 8 * 8)) + 4 * align256(n * 4) + align256(n * 16 * 8 * 4);
+}
+
+struct Carver {
+    char *base;
+    size_t used, cap;
+    void *take(size_t bytes) {
+        const size_t b = align256(bytes);
+        if (used + b > cap) return nullptr;
+        void *p = base + used;
+        used += b;
+        return p;
+    }
+};
+
+}  // namespace cfd
+
+using namespace cfd;
+
+struct cfd_ctx {
+    Ctx c;
+};
+
+#define CTX(ctx)                                                \
+    if (!(ctx)) { cfd::set_error("null context"); return CFD_E_ARG; } \
+    Ctx *c = &(ctx)->c;                                         \
+    if (hipSetDevice(c->device) != hipSuccess) { cfd::set_error("hipSetDevice failed"); return CFD_E_HIP; }
+
+#define NEED_MESH()                                                           \
+    if (!c->mesh_set) { cfd::set_error("mesh not uploaded"); return CFD_E_STATE; }
+
+extern "C" {
+
+const char *cfd_last_error(void) { return cfd::g_err; }
+int cfd_version(void) { return 100; }
+
+size_t cfd_workspace_bytes(int ni, int nj) {
+    if (ni < 1 || nj < 1) return 0;
+    return workspace_bytes_impl(ni, nj, bc_bytes_for(ni, nj));
+}
+
+int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes) {
+    if (!out || ni < 1 || nj < 1) { set_error("cfd_create: bad arguments"); return CFD_E_ARG; }
+    CFD_HIP(hipSetDevice(device));
+    cfd_ctx *h = new (std::nothrow) cfd_ctx();
+    if (!h) { set_error("out of host memory"); return CFD_E_ARG; }
+    Ctx *c = &h->c;
+    c->device = device;
+    const size_t need = cfd_workspace_bytes(ni, nj);
+    if (workspace) {
+        if (workspace_bytes < need || ((uintptr_t)workspace & 255)) {
+            set_error("workspace too small or not 256-byte aligned (need %zu bytes)", need);
+            delete h;
+            return CFD_E_ARG;
+        }
+        c->ws = (char *)workspace;
+        c->own_ws = false;
+    } else {
+        hipError_t e = hipMalloc((void **)&c->ws, need);
+        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); delete h; return CFD_E_HIP; }
+        c->own_ws = true;
+    }
+    c->ws_bytes = need;
+    hipError_t e = hipStreamCreate(&c->stream);
+    if (e != hipSuccess) { set_error("hipStreamCreate failed"); if (c->own_ws) hipFree(c->ws); delete h; return CFD_E_HIP; }
+    c->own_stream = true;
+    e = hipMemsetAsync(c->ws, 0, need, c->stream);
+    if (e != hipSuccess) { set_error("hipMemset failed"); return CFD_E_HIP; }
+
+    const std::vector<Geo> lv = level_geometry(ni, nj);
+    c->g = lv[0];
+    Carver cv{c->ws, 0, need};
+    const size_t pb = c->g.plane_elems() * sizeof(double);
+    auto plane = [&]() { return (double *)cv.take(pb); };
+    c->m_vol = plane(); c->m_wri = plane(); c->m_wnj = plane(); c->m_nix = plane(); c->m_niy = plane();
+    c->m_njx = plane(); c->m_njy = plane(); c->m_si = plane(); c->m_sj = plane(); c->m_di = plane();
+    c->m_dj = plane(); c->m_lmin = plane();
+    for (int s = 0; s < 2; ++s) { c->u[s] = plane(); c->v[s] = plane(); c->p[s] = plane(); }
+    c->su = plane(); c->sv = plane(); c->sp = plane();
+    c->k = plane(); c->omega = plane(); c->nut = plane(); c->pcorr = plane();
+    c->ap = plane(); c->ai = plane(); c->aj = plane();
+    c->tp = plane(); c->ti = plane(); c->tj = plane();
+    c->bu = plane(); c->bv = plane();
+    c->stage_a = plane(); c->stage_b = plane();   // contiguous: stage_a spans two planes
+    for (int q = 0; q < 16; ++q) c->kry[q] = plane();
+    c->levels.resize(lv.size());
+    c->levels[0].g = lv[0];
+    c->levels[0].ci = plane(); c->levels[0].cj = plane(); c->levels[0].D = plane();
+    c->levels[0].x = nullptr; c->levels[0].b = nullptr; c->levels[0].t = nullptr;
+    for (size_t l = 1; l < lv.size(); ++l) {
+        Level &L = c->levels[l];
+        L.g = lv[l];
+        const size_t lb = L.g.plane_elems() * sizeof(double);
+        L.ci = (double *)cv.take(lb); L.cj = (double *)cv.take(lb); L.D = (double *)cv.take(lb);
+        L.x = (double *)cv.take(lb); L.b = (double *)cv.take(lb); L.t = (double *)cv.take(lb);
+    }
+    c->partials = (double *)cv.take((size_t)4 * MAX_PARTIALS * sizeof(double));
+    c->scal = (double *)cv.take(2048);
+    c->bc_buf = (char *)cv.take(bc_bytes_for(ni, nj));
+    if (!c->bc_buf) { set_error("internal: workspace carve overflow"); return CFD_E_ARG; }
+    c->ws_used = cv.used;
+    e = hipHostMalloc((void **)&c->h_scal, 256 * sizeof(double));
+    if (e != hipSuccess) { set_error("hipHostMalloc failed"); return CFD_E_HIP; }
+    // carve the BC buffer
+    {
+        const size_t n = (size_t)(ni > nj ? ni : nj);
+        Carver bcv{c->bc_buf, 0, bc_bytes_for(ni, nj)};
+        for (int s = 0; s < 4; ++s) {
+            char *blk = (char *)bcv.take(n * (2 * 4 + 8 * 8));
+            FlowBCSide &S = c->fbc.side[s];
+            double *d = (double *)blk;
+            S.ua = d; S.ub = d + n; S.va = d + 2 * n; S.vb = d + 3 * n; S.pa = d + 4 * n; S.pb = d + 5 * n;
+            S.nx = d + 6 * n; S.ny = d + 7 * n;
+            int32_t *ip = (int32_t *)(d + 8 * n);
+            S.kind_uv = ip; S.kind_p = ip + n;
+            S.n = 0;
+        }
+        for (int s = 0; s < 4; ++s) c->pmask[s] = (int32_t *)bcv.take(n * 4);
+        c->n_turb_vals = (int)(n * 16 * 4);
+        c->turb_vals = (double *)bcv.take((size_t)c->n_turb_vals * 8);
+    }
+    CFD_HIP(hipEventCreate(&c->ev0));
+    CFD_HIP(hipEventCreate(&c->ev1));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    *out = h;
+    return CFD_OK;
+}
+
+int cfd_destroy(cfd_ctx *ctx) {
+    if (!ctx) return CFD_OK;
+    Ctx *c = &ctx->c;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->h_scal) hipHostFree(c->h_scal);
+    if (c->own_ws && c->ws) hipFree(c->ws);
+    delete ctx;
+    return CFD_OK;
+}
+
+int cfd_set_stream(cfd_ctx *ctx, void *hip_stream) {
+    CTX(ctx);
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream) { hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = (hipStream_t)hip_stream;
+    return CFD_OK;
+}
+
+int cfd_synchronize(cfd_ctx *ctx) {
+    CTX(ctx);
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+int cfd_pitch(cfd_ctx *ctx) { return ctx ? ctx->c.g.pitch : 0; }
+
+static double *field_plane(Ctx *c, int id) {
+    switch (id) {
+        case CFD_F_U: return c->U();
+        case CFD_F_V: return c->V();
+        case CFD_F_P: return c->P();
+        case CFD_F_K: return c->k;
+        case CFD_F_OMEGA: return c->omega;
+        case CFD_F_NUT: return c->nut;
+        case CFD_F_PCORR: return c->pcorr;
+        case CFD_F_AP: return c->ap;
+        case CFD_F_AI: return c->ai;
+        case CFD_F_AJ: return c->aj;
+        case CFD_F_BU: return c->bu;
+        case CFD_F_BV: return c->bv;
+        default: return nullptr;
+    }
+}
+
+int64_t cfd_field_offset(cfd_ctx *ctx, int field_id) {
+    if (!ctx) return -1;
+    double *p = field_plane(&ctx->c, field_id);
+    return p ? (int64_t)((char *)p - ctx->c.ws) : -1;
+}
+
+// ------------------------------------------------------------------ mesh
+int cfd_upload_mesh(cfd_ctx *ctx, const double *cell_volume, const double *w_right_i, const double *w_north_j,
+                    const double *face_normal_i, const double *face_normal_j, const double *diff_d_i,
+                    const double *diff_d_j, const double *cell_spacing_i, const double *cell_spacing_j) {
+    CTX(ctx);
+    if (!cell_volume || !w_right_i || !w_north_j || !face_normal_i || !face_normal_j || !diff_d_i || !diff_d_j ||
+        !cell_spacing_i || !cell_spacing_j) { set_error("cfd_upload_mesh: null array"); return CFD_E_ARG; }
+    const Geo g = c->g;
+    CFD_TRY(to_device(c, cell_volume, c->m_vol, CFD_KIND_CELL));
+    CFD_TRY(to_device(c, w_right_i, c->m_wri, CFD_KIND_FACE_I));
+    CFD_TRY(to_device(c, w_north_j, c->m_wnj, CFD_KIND_FACE_J));
+    CFD_TRY(to_device(c, diff_d_i, c->m_di, CFD_KIND_FACE_I));
+    CFD_TRY(to_device(c, diff_d_j, c->m_dj, CFD_KIND_FACE_J));
+    { double *pl[2] = {c->m_nix, c->m_niy}; CFD_TRY(to_device_comp(c, face_normal_i, 2, pl, CFD_KIND_FACE_I)); }
+    { double *pl[2] = {c->m_njx, c->m_njy}; CFD_TRY(to_device_comp(c, face_normal_j, 2, pl, CFD_KIND_FACE_J)); }
+    // |S| = hypot(nx, ny) and min(spacing_i, spacing_j) are formed on the host exactly as numpy
+    // does (solver.py:154-155, 568-570) so that the device planes carry the reference's bits.
+    std::vector<double> tmp((size_t)(g.ni + 1) * (g.nj + 1));
+    for (size_t q = 0; q < (size_t)(g.ni + 1) * g.nj; ++q) tmp[q] = hypot(face_normal_i[2 * q], face_normal_i[2 * q + 1]);
+    CFD_TRY(to_device(c, tmp.data(), c->m_si, CFD_KIND_FACE_I));
+    for (size_t q = 0; q < (size_t)g.ni * (g.nj + 1); ++q) tmp[q] = hypot(face_normal_j[2 * q], face_normal_j[2 * q + 1]);
+    CFD_TRY(to_device(c, tmp.data(), c->m_sj, CFD_KIND_FACE_J));
+    for (size_t q = 0; q < (size_t)g.ni * g.nj; ++q) tmp[q] = std::min(cell_spacing_i[q], cell_spacing_j[q]);
+    CFD_TRY(to_device(c, tmp.data(), c->m_lmin, CFD_KIND_CELL));
+    c->mesh_set = true;
+    c->p_built = false;
+    return CFD_OK;
+}
+
+int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node) {
+    CTX(ctx);
+    if (!node) { set_error("cfd_mesh_from_nodes: null"); return CFD_E_ARG; }
+    const Geo g = c->g;
+    // nodes (Ni+1, Nj+1, 2) -> two staging planes [jn][in] via the ghosted-cell transposer
+    // (node (a, b) lands at plane index at(a, b)); kry[13], kry[14] hold x and y.
+    const int n0 = g.ni + 1, n1 = g.nj + 1;
+    const size_t bytes = (size_t)n0 * n1 * 2 * sizeof(double);
+    CFD_HIP(hipMemcpyAsync(c->stage_a, node, bytes, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((n1 + 31) / 32, (n0 + 31) / 32), blk(32, 8);
+    hipLaunchKernelGGL((k_transpose<true>), grid, blk, 0, c->stream, g, n0, n1, 2, 0, 0, c->stage_a, c->kry[13]);
+    hipLaunchKernelGGL((k_transpose<true>), grid, blk, 0, c->stream, g, n0, n1, 2, 1, 0, c->stage_a, c->kry[14]);
+    CFD_HIP(hipGetLastError());
+    // plane index of node (a, b) is b * pitch + a + 1
+    CFD_TRY(launch_metrics_from_nodes(c, c->kry[13] + 1, c->kry[14] + 1, g.pitch));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    c->mesh_set = true;
+    c->p_built = false;
+    return CFD_OK;
+}
+
+int cfd_mesh_from_rect(cfd_ctx *ctx, const double *x_nodes, const double *y_nodes) {
+    CTX(ctx);
+    if (!x_nodes || !y_nodes) { set_error("cfd_mesh_from_rect: null"); return CFD_E_ARG; }
+    const Geo g = c->g;
+    double *dx = c->stage_a, *dy = c->stage_a + (g.ni + 8);
+    CFD_HIP(hipMemcpyAsync(dx, x_nodes, (size_t)(g.ni + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CFD_HIP(hipMemcpyAsync(dy, y_nodes, (size_t)(g.nj + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CFD_TRY(launch_metrics_from_rect(c, dx, dy));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    c->mesh_set = true;
+    c->p_built = false;
+    return CFD_OK;
+}
+
+int cfd_download_mesh_plane(cfd_ctx *ctx, int plane_id, double *host) {
+    CTX(ctx);
+    NEED_MESH();
+    double *pl[12] = {c->m_vol, c->m_wri, c->m_wnj, c->m_nix, c->m_niy, c->m_njx, c->m_njy, c->m_si, c->m_sj, c->m_di, c->m_dj, c->m_lmin};
+    const int kinds[12] = {CFD_KIND_CELL, CFD_KIND_FACE_I, CFD_KIND_FACE_J, CFD_KIND_FACE_I, CFD_KIND_FACE_I, CFD_KIND_FACE_J,
+                           CFD_KIND_FACE_J, CFD_KIND_FACE_I, CFD_KIND_FACE_J, CFD_KIND_FACE_I, CFD_KIND_FACE_J, CFD_KIND_CELL};
+    if (plane_id < 0 || plane_id >= 12 || !host) { set_error("bad mesh plane id"); return CFD_E_ARG; }
+    return from_device(c, pl[plane_id], host, kinds[plane_id]);
+}
+
+// ------------------------------------------------------------------ fields
+int cfd_upload_field(cfd_ctx *ctx, int field_id, const double *host, int kind) {
+    CTX(ctx);
+    double *pl = field_plane(c, field_id);
+    if (!pl || !host || kind < 0 || kind > 3) { set_error("cfd_upload_field: bad arguments"); return CFD_E_ARG; }
+    CFD_TRY(to_device(c, host, pl, kind));
+    // u, v, p exist twice (ping-pong): keep never-written ghosts (corners) identical in both
+    if (field_id == CFD_F_U) CFD_TRY(launch_copy_plane(c, pl, c->U1()));
+    if (field_id == CFD_F_V) CFD_TRY(launch_copy_plane(c, pl, c->V1()));
+    if (field_id == CFD_F_P) CFD_TRY(launch_copy_plane(c, pl, c->P1()));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+int cfd_download_field(cfd_ctx *ctx, int field_id, double *host, int kind) {
+    CTX(ctx);
+    double *pl = field_plane(c, field_id);
+    if (!pl || !host || kind < 0 || kind > 3) { set_error("cfd_download_field: bad arguments"); return CFD_E_ARG; }
+    return from_device(c, pl, host, kind);
+}
+
+// ------------------------------------------------------------------ parameters
+int cfd_set_physics(cfd_ctx *ctx, double nu, double dpdx, double dpdy, int rhie_chow, int turbulent) {
+    CTX(ctx);
+    c->nu = nu; c->dpdx = dpdx; c->dpdy = dpdy; c->rhie_chow = rhie_chow ? 1 : 0; c->turbulent = turbulent ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, int p_maxiter, double turb_tol,
+                   int turb_maxiter, int freeze_pressure) {
+    CTX(ctx);
+    if (mom_tol < 0 || p_tol < 0 || turb_tol < 0 || mom_maxiter < 1 || p_maxiter < 1 || turb_maxiter < 1) {
+        set_error("cfd_set_solver: bad tolerances"); return CFD_E_ARG;
+    }
+    c->mom_tol = mom_tol; c->mom_maxiter = mom_maxiter; c->p_tol = p_tol; c->p_maxiter = p_maxiter;
+    c->turb_tol = turb_tol; c->turb_maxiter = turb_maxiter; c->freeze_pressure = freeze_pressure ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int min_size) {
+    CTX(ctx);
+    (void)min_size;   // the hierarchy shape is fixed at cfd_create (coarsen while a dimension > 4)
+    if (nu_pre < 1 || nu_post < 0 || !(omega > 0.0 && omega <= 1.0) || coarse_sweeps < 1) {
+        set_error("cfd_set_multigrid: bad parameters"); return CFD_E_ARG;
+    }
+    c->mg_pre = nu_pre; c->mg_post = nu_post; c->mg_omega = omega; c->mg_coarse_sweeps = coarse_sweeps;
+    return CFD_OK;
+}
+
+int cfd_set_turbulence_clip(cfd_ctx *ctx, double k_min, double omega_min) {
+    CTX(ctx);
+    c->k_clip = k_min; c->omega_clip = omega_min;
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------ boundary tables
+int cfd_set_flow_bc(cfd_ctx *ctx, int side, int n, const int32_t *kind_uv, const int32_t *kind_p, const double *ua,
+                    const double *ub, const double *va, const double *vb, const double *pa, const double *pb,
+                    const double *nx, const double *ny) {
+    CTX(ctx);
+    if (side < 0 || side > 3) { set_error("bad side"); return CFD_E_ARG; }
+    const int want = side < 2 ? c->g.nj : c->g.ni;
+    if (n != want) { set_error("flow BC table for side %d needs %d entries, got %d", side, want, n); return CFD_E_ARG; }
+    FlowBCSide &S = c->fbc.side[side];
+    const void *src[10] = {ua, ub, va, vb, pa, pb, nx, ny, kind_uv, kind_p};
+    void *dst[10] = {(void *)S.ua, (void *)S.ub, (void *)S.va, (void *)S.vb, (void *)S.pa, (void *)S.pb, (void *)S.nx,
+                     (void *)S.ny, (void *)S.kind_uv, (void *)S.kind_p};
+    for (int q = 0; q < 10; ++q) {
+        if (!src[q]) { set_error("cfd_set_flow_bc: null array"); return CFD_E_ARG; }
+        CFD_HIP(hipMemcpyAsync(dst[q], src[q], (size_t)n * (q < 8 ? 8 : 4), hipMemcpyHostToDevice, c->stream));
+    }
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    S.n = n;
+    c->fbc_set[side] = true;
+    return CFD_OK;
+}
+
+int cfd_set_periodicity(cfd_ctx *ctx, int per_i, int per_j, int wrap_p_i, int wrap_p_j) {
+    CTX(ctx);
+    c->per_i = per_i ? 1 : 0; c->per_j = per_j ? 1 : 0; c->wrap_p_i = wrap_p_i ? 1 : 0; c->wrap_p_j = wrap_p_j ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_set_pressure_bc(cfd_ctx *ctx, const int32_t *mask_imin, const int32_t *mask_imax, const int32_t *mask_jmin,
+                        const int32_t *mask_jmax, int per_i, int per_j, int has_dirichlet, int pin_i, int pin_j,
+                        double pin_value) {
+    CTX(ctx);
+    const int32_t *m[4] = {mask_imin, mask_imax, mask_jmin, mask_jmax};
+    for (int s = 0; s < 4; ++s) {
+        const size_t n = s < 2 ? c->g.nj : c->g.ni;
+        if (m[s]) CFD_HIP(hipMemcpyAsync(c->pmask[s], m[s], n * 4, hipMemcpyHostToDevice, c->stream));
+        else CFD_HIP(hipMemsetAsync(c->pmask[s], 0, n * 4, c->stream));
+    }
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    if (!has_dirichlet && (pin_i < 0 || pin_i >= c->g.ni || pin_j < 0 || pin_j >= c->g.nj)) {
+        set_error("pressure reference cell (%d, %d) outside the grid", pin_i, pin_j); return CFD_E_ARG;
+    }
+    c->pp_per_i = per_i ? 1 : 0; c->pp_per_j = per_j ? 1 : 0; c->has_dirichlet = has_dirichlet ? 1 : 0;
+    c->pin_i = pin_i; c->pin_j = pin_j; c->pin_value = pin_value;
+    c->pbc_set = true;
+    c->p_built = false;
+    return CFD_OK;
+}
+
+int cfd_set_turb_bc(cfd_ctx *ctx, int n_ops, const cfd_turb_op *ops, int n_values, const double *values) {
+    CTX(ctx);
+    if (n_ops < 0 || n_values < 0 || n_values > c->n_turb_vals || (n_ops && !ops) || (n_values && !values)) {
+        set_error("cfd_set_turb_bc: bad arguments (max %d values)", c->n_turb_vals); return CFD_E_ARG;
+    }
+    for (int q = 0; q < n_ops; ++q) {
+        const cfd_turb_op &o = ops[q];
+        const int nmax = (o.op == CFD_TOP_WRAP_I || o.op == CFD_TOP_WRAP_J) ? 0 : ((o.side < 2 ? c->g.nj : c->g.ni) - 1);
+        const bool wrap = o.op == CFD_TOP_WRAP_I || o.op == CFD_TOP_WRAP_J;
+        if (o.op < 0 || o.op > 3 || (!wrap && (o.side < 0 || o.side > 3 || o.lo < 0 || o.hi < o.lo || o.hi > nmax ||
+            o.value_off < 0 || o.value_off + (o.hi - o.lo + 1) > n_values || (o.field != CFD_F_K && o.field != CFD_F_OMEGA)))) {
+            set_error("cfd_set_turb_bc: op %d malformed", q); return CFD_E_ARG;
+        }
+    }
+    c->turb_ops.assign(ops, ops + n_ops);
+    if (n_values) CFD_HIP(hipMemcpyAsync(c->turb_vals, values, (size_t)n_values * 8, hipMemcpyHostToDevice, c->stream));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------ phase timing
+struct Phase {
+    Ctx *c;
+    int id;
+    Phase(Ctx *c_, int id_) : c(c_), id(id_) { if (c->timing) hipEventRecord(c->ev0, c->stream); }
+    ~Phase() {
+        if (!c->timing) return;
+        hipEventRecord(c->ev1, c->stream);
+        hipEventSynchronize(c->ev1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->phase_us[id] += 1000.0 * ms;
+    }
+};
+enum { PH_BC = 0, PH_ADV, PH_MOM, PH_PRESS, PH_CORR, PH_CONT, PH_TURB, PH_DT };
+
+int cfd_enable_phase_timing(cfd_ctx *ctx, int on) { CTX(ctx); c->timing = on != 0; return CFD_OK; }
+int cfd_phase_times(cfd_ctx *ctx, double out[8], int reset) {
+    CTX(ctx);
+    for (int q = 0; q < 8; ++q) { out[q] = c->phase_us[q]; if (reset) c->phase_us[q] = 0.0; }
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------ step pieces
+static int ready(Ctx *c) {
+    if (!c->mesh_set) { set_error("mesh not uploaded"); return CFD_E_STATE; }
+    for (int s = 0; s < 4; ++s)
+        if (!c->fbc_set[s]) { set_error("flow BC table of side %d not set", s); return CFD_E_STATE; }
+    if (!c->pbc_set) { set_error("pressure BCs not set"); return CFD_E_STATE; }
+    return CFD_OK;
+}
+
+static int do_predictor(Ctx *c, double dt, double res[3]) {
+    {
+        Phase ph(c, PH_ADV);
+        CFD_TRY(launch_eddy_viscosity(c));
+        CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+        c->dt_ap = dt;
+        CFD_TRY(launch_momentum_rhs(c, dt, c->U(), c->V(), c->P()));
+    }
+    {
+        Phase ph(c, PH_MOM);
+        const OpDev op{c->ai, c->aj, c->ap, c->g, c->per_i, c->per_j};
+        double *b[2] = {c->bu, c->bv}, *x[2] = {c->U1(), c->V1()};
+        double rms[2];
+        int it = 0;
+        CFD_TRY(momentum_like_solve(c, op, b, x, 2, c->mom_tol, c->mom_maxiter, &it, c->stats.mom_relres, rms));
+        c->stats.mom_iters = it;
+        res[1] = rms[0];
+        res[2] = rms[1];
+    }
+    return CFD_OK;
+}
+
+static int do_pressure(Ctx *c, const double *u, const double *v, const double *p) {
+    Phase ph(c, PH_PRESS);
+    if (!c->p_built || !c->freeze_pressure) CFD_TRY(build_pressure_hierarchy(c));
+    double *b = c->kry[0];
+    CFD_TRY(launch_pressure_rhs(c, u, v, p, b));
+    int it = 0;
+    double rr = 0;
+    CFD_TRY(pressure_solve(c, b, c->kry[10], c->p_tol, c->p_maxiter, &it, &rr));
+    c->stats.p_iters = it;
+    c->stats.p_relres = rr;
+    // interior of p_corr := solution (ghosts are set by the p' BC kernel)
+    CFD_HIP(hipMemcpy2DAsync(c->pcorr + c->g.at(0, 1), c->g.pitch * sizeof(double), c->kry[10] + c->g.at(0, 1),
+                             c->g.pitch * sizeof(double), (size_t)(c->g.ni + 2) * sizeof(double), c->g.nj,
+                             hipMemcpyDeviceToDevice, c->stream));
+    return CFD_OK;
+}
+
+int cfd_apply_flow_bc(cfd_ctx *ctx) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    Phase ph(c, PH_BC);
+    return launch_flow_bc(c, c->U(), c->V(), c->P());
+}
+
+int cfd_compute_dt(cfd_ctx *ctx, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double dt_min,
+                   int use_dt_max, double dt_max, double out[3]) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    Phase ph(c, PH_DT);
+    double m[2];
+    CFD_TRY(launch_dt(c, use_cfl, cfl, use_cfl_diff, cfl_diff, m));
+    const double dt_adv = use_cfl ? m[0] : INFINITY, dt_diff = use_cfl_diff ? m[1] : INFINITY;
+    double dt = std::min(dt_adv, dt_diff);
+    if (!std::isfinite(dt)) dt = use_dt_max ? dt_max : dt;
+    dt = std::max(dt, dt_min);
+    if (use_dt_max) dt = std::min(dt, dt_max);
+    out[0] = dt; out[1] = dt_adv; out[2] = dt_diff;
+    return CFD_OK;
+}
+
+int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, double relax_p, double res[3]) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!(dt > 0.0)) { set_error("dt must be positive"); return CFD_E_ARG; }
+    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U(), c->V(), c->P())); }
+    CFD_TRY(do_predictor(c, dt, res));
+    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U1(), c->V1(), c->P())); }
+    CFD_TRY(do_pressure(c, c->U1(), c->V1(), c->P()));
+    {
+        Phase ph(c, PH_CORR);
+        CFD_TRY(launch_pcorr_bc(c));
+        CFD_TRY(launch_correct(c, c->U1(), c->V1(), c->U(), c->V(), c->P(), c->U1(), c->V1(), c->P1(), relax_u, relax_v, relax_p));
+        c->cur ^= 1;
+    }
+    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U(), c->V(), c->P())); }
+    { Phase ph(c, PH_CONT); CFD_TRY(launch_continuity(c, c->U(), c->V(), c->P(), &res[0])); }
+    return CFD_OK;
+}
+
+int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, double relax_v, double relax_p,
+                  double res[3]) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!(dt > 0.0) || n_correctors < 1) { set_error("cfd_piso_step: bad arguments"); return CFD_E_ARG; }
+    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U(), c->V(), c->P())); }
+    CFD_TRY(do_predictor(c, dt, res));
+    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U1(), c->V1(), c->P())); }
+    const double *pcur = c->P();
+    for (int n = 0; n < n_correctors; ++n) {
+        CFD_TRY(do_pressure(c, c->U1(), c->V1(), pcur));
+        {
+            Phase ph(c, PH_CORR);
+            CFD_TRY(launch_pcorr_bc(c));
+            CFD_TRY(launch_correct(c, c->U1(), c->V1(), c->U(), c->V(), c->P(), c->U1(), c->V1(), c->P1(), relax_u, relax_v, relax_p));
+        }
+        pcur = c->P1();
+        { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U1(), c->V1(), c->P1())); }
+    }
+    c->cur ^= 1;
+    { Phase ph(c, PH_CONT); CFD_TRY(launch_continuity(c, c->U(), c->V(), c->P(), &res[0])); }
+    return CFD_OK;
+}
+
+int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!c->turbulent) { set_error("turbulence is disabled"); return CFD_E_STATE; }
+    Phase ph(c, PH_TURB);
+    CFD_TRY(launch_turb_bc(c));
+    CFD_TRY(launch_eddy_viscosity(c));
+    CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+    c->dt_ap = dt;
+    CFD_TRY(launch_diffusion_ap(c, dt, 0.5, c->ti, c->tj, c->tp));
+    CFD_TRY(launch_turb_rhs(c, dt));
+    const OpDev op{c->ti, c->tj, c->tp, c->g, c->per_i, c->per_j};
+    double *b[2] = {c->bu, c->bv}, *x[2] = {c->k, c->omega};
+    int it = 0;
+    CFD_TRY(momentum_like_solve(c, op, b, x, 2, c->turb_tol, c->turb_maxiter, &it, c->stats.k_relres, nullptr));
+    c->stats.k_iters = it;
+    CFD_TRY(launch_clip(c, c->k, c->k_clip));
+    CFD_TRY(launch_clip(c, c->omega, c->omega_clip));
+    CFD_TRY(launch_turb_bc(c));
+    return CFD_OK;
+}
+
+int cfd_get_stats(cfd_ctx *ctx, cfd_solve_stats *out) {
+    CTX(ctx);
+    if (!out) return CFD_E_ARG;
+    *out = c->stats;
+    return CFD_OK;
+}
+
+int cfd_bulk_velocity(cfd_ctx *ctx, int field_id, double *out) {
+    CTX(ctx);
+    NEED_MESH();
+    double *f = field_plane(c, field_id);
+    if (!f || !out) return CFD_E_ARG;
+    double s[2];
+    CFD_TRY(launch_weighted_sum(c, f, c->m_vol, s));
+    *out = s[0] / s[1];
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------ fine-grained entry points
+int cfd_eddy_viscosity(cfd_ctx *ctx) { CTX(ctx); return launch_eddy_viscosity(c); }
+
+int cfd_momentum_diagonal(cfd_ctx *ctx, double dt, double nut_coef) {
+    CTX(ctx);
+    NEED_MESH();
+    CFD_TRY(launch_diffusion_ap(c, dt, nut_coef, c->ai, c->aj, c->ap));
+    c->dt_ap = dt;
+    return CFD_OK;
+}
+
+int cfd_face_flux(cfd_ctx *ctx, int rhie_chow, int use_peff, double *flux_i, double *flux_j) {
+    CTX(ctx);
+    NEED_MESH();
+    CFD_TRY(launch_face_flux(c, c->U(), c->V(), c->P(), rhie_chow, use_peff && c->turbulent, c->kry[11], c->kry[12]));
+    CFD_TRY(from_device(c, c->kry[11], flux_i, CFD_KIND_FACE_I));
+    return from_device(c, c->kry[12], flux_j, CFD_KIND_FACE_J);
+}
+
+int cfd_grad(cfd_ctx *ctx, int field_id, double *grad) {
+    CTX(ctx);
+    NEED_MESH();
+    double *f = field_plane(c, field_id);
+    if (!f || !grad) return CFD_E_ARG;
+    CFD_TRY(launch_grad(c, f, c->kry[11], c->kry[12]));
+    double *pl[2] = {c->kry[11], c->kry[12]};
+    return from_device_comp(c, pl, 2, grad, CFD_KIND_CELL);
+}
+
+int cfd_advect(cfd_ctx *ctx, int field_id, const double *flux_i, const double *flux_j, double *out) {
+    CTX(ctx);
+    NEED_MESH();
+    double *f = field_plane(c, field_id);
+    if (!f || !flux_i || !flux_j || !out) return CFD_E_ARG;
+    CFD_TRY(to_device(c, flux_i, c->kry[11], CFD_KIND_FACE_I));
+    CFD_TRY(to_device(c, flux_j, c->kry[12], CFD_KIND_FACE_J));
+    CFD_TRY(launch_advect(c, f, c->kry[11], c->kry[12], c->kry[13]));
+    return from_device(c, c->kry[13], out, CFD_KIND_CELL);
+}
+
+int cfd_momentum_rhs(cfd_ctx *ctx, double dt) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    return launch_momentum_rhs(c, dt, c->U(), c->V(), c->P());
+}
+
+int cfd_momentum_solve(cfd_ctx *ctx, double res[2]) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    const OpDev op{c->ai, c->aj, c->ap, c->g, c->per_i, c->per_j};
+    double *b[2] = {c->bu, c->bv}, *x[2] = {c->U1(), c->V1()};
+    int it = 0;
+    CFD_TRY(momentum_like_solve(c, op, b, x, 2, c->mom_tol, c->mom_maxiter, &it, c->stats.mom_relres, res));
+    c->stats.mom_iters = it;
+    // the fine-grained API works in place on the current planes (like the reference): copy the interior
+    for (int q = 0; q < 2; ++q) {
+        double *dst = q == 0 ? c->U() : c->V();
+        CFD_HIP(hipMemcpy2DAsync(dst + c->g.at(1, 1), c->g.pitch * sizeof(double), x[q] + c->g.at(1, 1),
+                                 c->g.pitch * sizeof(double), (size_t)c->g.ni * sizeof(double), c->g.nj,
+                                 hipMemcpyDeviceToDevice, c->stream));
+    }
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+int cfd_pressure_solve(cfd_ctx *ctx) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    CFD_TRY(do_pressure(c, c->U(), c->V(), c->P()));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+int cfd_download_pressure_system(cfd_ctx *ctx, double *c_i, double *c_j, double *diag, double *rhs) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!c->p_built) CFD_TRY(build_pressure_hierarchy(c));
+    const Level &L = c->levels[0];
+    if (c_i) CFD_TRY(from_device(c, L.ci, c_i, CFD_KIND_FACE_I));
+    if (c_j) CFD_TRY(from_device(c, L.cj, c_j, CFD_KIND_FACE_J));
+    if (diag) CFD_TRY(from_device(c, L.D, diag, CFD_KIND_CELL));
+    if (rhs) {
+        CFD_TRY(launch_pressure_rhs(c, c->U(), c->V(), c->P(), c->kry[0]));
+        CFD_TRY(from_device(c, c->kry[0], rhs, CFD_KIND_CELL));
+    }
+    return CFD_OK;
+}
+
+int cfd_snapshot(cfd_ctx *ctx) {
+    CTX(ctx);
+    CFD_TRY(launch_copy_plane(c, c->U(), c->su));
+    CFD_TRY(launch_copy_plane(c, c->V(), c->sv));
+    return launch_copy_plane(c, c->P(), c->sp);
+}
+
+int cfd_correct(cfd_ctx *ctx, double relax_u, double relax_v, double relax_p) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    CFD_TRY(launch_pcorr_bc(c));
+    CFD_TRY(launch_correct(c, c->U(), c->V(), c->su, c->sv, c->sp, c->U(), c->V(), c->P(), relax_u, relax_v, relax_p));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+int cfd_continuity(cfd_ctx *ctx, double *out) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    return launch_continuity(c, c->U(), c->V(), c->P(), out);
+}
+
+int cfd_apply_turb_bc(cfd_ctx *ctx) {
+    CTX(ctx);
+    NEED_MESH();
+    CFD_TRY(launch_turb_bc(c));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+// ------------------------------------------------------------------ linear-algebra entry points
+int cfd_spmv(cfd_ctx *ctx, int which, const double *x, double *y) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!x || !y) return CFD_E_ARG;
+    OpDev op{c->ai, c->aj, c->ap, c->g, c->per_i, c->per_j};
+    if (which == 1) {
+        if (!c->p_built) CFD_TRY(build_pressure_hierarchy(c));
+        const Level &L = c->levels[0];
+        op = OpDev{L.ci, L.cj, L.D, c->g, c->pp_per_i, c->pp_per_j};
+    }
+    CFD_TRY(to_device(c, x, c->kry[11], CFD_KIND_CELL));
+    CFD_TRY(launch_spmv(c, op, c->kry[11], c->kry[12]));
+    return from_device(c, c->kry[12], y, CFD_KIND_CELL);
+}
+
+int cfd_vcycle(cfd_ctx *ctx, const double *r, double *z) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!c->p_built) CFD_TRY(build_pressure_hierarchy(c));
+    CFD_TRY(to_device(c, r, c->kry[11], CFD_KIND_CELL));
+    CFD_TRY(vcycle(c, c->kry[11], c->kry[12]));
+    return from_device(c, c->kry[12], z, CFD_KIND_CELL);
+}
+
+int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, int maxiter, int *iters, double *relres) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!c->p_built) CFD_TRY(build_pressure_hierarchy(c));
+    CFD_TRY(to_device(c, b, c->kry[11], CFD_KIND_CELL));
+    int it = 0;
+    double rr = 0;
+    CFD_TRY(pressure_solve(c, c->kry[11], c->kry[12], tol, maxiter, &it, &rr));
+    if (iters) *iters = it;
+    if (relres) *relres = rr;
+    return from_device(c, c->kry[12], x, CFD_KIND_CELL);
+}
+
+int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us) {
+    CTX(ctx);
+    CFD_TRY(ready(c));
+    if (!avg_us) return CFD_E_ARG;
+    return time_kernel(c, kernel, reps, avg_us);
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+// Internal declarations shared by the HIP translation units of libcfd_hip.so.
+// gfx950 only.  Device layout: planes [jg][ig], ig contiguous; element (ig, jg) of a
+// ghosted (Ni+2) x (Nj+2) plane lives at jg * pitch + ig + 1 so that interior cell
+// i = 0 (ig = 1) is 16-byte aligned.  Face planes share the geometry: i-face f (west
+// face of cell f) sits at the index of cell f, j-face g (south face) at cell g.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/cfd_hip.h"
+
+namespace cfd {
+
+constexpr double TINY = 1.0e-14;
+constexpr double K_FLOOR = 1.0e-15;      // turbulence.py:28
+constexpr double OMEGA_FLOOR = 1.0e-6;   // turbulence.py:29
+constexpr int MAX_PARTIALS = 4096;
+constexpr int MAX_LEVELS = 24;
+
+struct Geo {
+    int ni, nj, pitch;
+    __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)jg * pitch + ig + 1; }
+    __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + 1) * pitch + i + 2; }
+    __host__ inline size_t plane_elems() const { return (size_t)(nj + 2) * pitch; }
+};
+
+inline int pitch_for(int ni) { return ((ni + 4) + 31) / 32 * 32; }
+
+struct MeshDev {
+    const double *vol, *wri, *wnj, *nix, *niy, *njx, *njy, *si, *sj, *di, *dj, *lmin;
+};
+
+// 5-point operator on masked or unmasked face planes.
+// (A x)_P = D x_P - ci[W] x_W - ci[E] x_E - cj[S] x_S - cj[N] x_N ; boundary couplings are
+// dropped unless the axis is periodic (then the x index wraps).
+struct OpDev {
+    const double *ci, *cj, *D;
+    Geo g;
+    int per_i, per_j;
+};
+
+struct FlowBCSide {
+    const int32_t *kind_uv, *kind_p;
+    const double *ua, *ub, *va, *vb, *pa, *pb, *nx, *ny;
+    int n;
+};
+
+struct FlowBCDev {
+    FlowBCSide side[4];
+};
+
+void set_error(const char *fmt, ...);
+
+#define CFD_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            cfd::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e__)); \
+            return CFD_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define CFD_TRY(expr)                 \
+    do {                              \
+        int rc__ = (expr);            \
+        if (rc__ != CFD_OK) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------ multigrid level
+struct Level {
+    Geo g;
+    double *ci, *cj, *D;     // operator planes (masked)
+    double *x, *b, *t;       // solution, right-hand side, scratch (Jacobi ping-pong)
+};
+
+// ------------------------------------------------------------------ context
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Geo g{};
+    char *ws = nullptr;          // workspace base
+    size_t ws_bytes = 0, ws_used = 0;
+    bool own_ws = false;
+
+    // mesh planes
+    double *m_vol, *m_wri, *m_wnj, *m_nix, *m_niy, *m_njx, *m_njy, *m_si, *m_sj, *m_di, *m_dj, *m_lmin;
+    bool mesh_set = false;
+
+    // field planes.  cur = 0/1 selects which of the two (u, v, p) sets is "current";
+    // the other one is the scratch that receives the momentum solution.
+    double *u[2], *v[2], *p[2];
+    int cur = 0;
+    double *su, *sv, *sp;        // explicit snapshot planes (PISO, fine-grained API)
+    double *k, *omega, *nut, *pcorr;
+    double *ap, *ai, *aj;        // momentum diagonal and face diffusion conductances
+    double *tp, *ti, *tj;        // same for the k/omega transport (nu + 0.5 nu_t)
+    double *bu, *bv;             // right-hand sides (momentum / k, omega)
+    double *stage_a, *stage_b;   // staging planes for host <-> device transposes
+    double *kry[16];             // Krylov work planes
+    int n_kry = 16;
+
+    // pressure operator (finest level = levels[0])
+    std::vector<Level> levels;
+    bool p_built = false;
+    bool p_symmetric = true;
+
+    // reductions
+    double *partials = nullptr;  // [q][MAX_PARTIALS]
+    double *scal = nullptr;      // device scalars
+    double *h_scal = nullptr;    // pinned host mirror
+    int n_red_blocks = 0;
+
+    // BC tables
+    char *bc_buf = nullptr;      // device buffer for flow tables
+    FlowBCDev fbc{};
+    bool fbc_set[4] = {false, false, false, false};
+    int per_i = 0, per_j = 0, wrap_p_i = 0, wrap_p_j = 0;
+    int32_t *pmask[4] = {nullptr, nullptr, nullptr, nullptr};
+    int pp_per_i = 0, pp_per_j = 0, has_dirichlet = 0, pin_i = 0, pin_j = 0;
+    double pin_value = 0.0;
+    bool pbc_set = false;
+    std::vector<cfd_turb_op> turb_ops;
+    double *turb_vals = nullptr;
+    int n_turb_vals = 0;
+
+    // parameters
+    double nu = 1e-3, dpdx = 0, dpdy = 0;
+    int rhie_chow = 1, turbulent = 0;
+    double mom_tol = 1e-8, p_tol = 1e-8, turb_tol = 1e-8;
+    int mom_maxiter = 200, p_maxiter = 200, turb_maxiter = 200, freeze_pressure = 1;
+    int mg_pre = 2, mg_post = 2, mg_coarse_sweeps = 40, mg_min = 4;
+    double mg_omega = 0.8;
+    double k_clip = 1e-10, omega_clip = 1e-10;
+    double dt_ap = -1.0;          // dt the a_P plane was built with
+
+    cfd_solve_stats stats{};
+
+    // phase timing
+    bool timing = false;
+    double phase_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    MeshDev mesh() const {
+        return MeshDev{m_vol, m_wri, m_wnj, m_nix, m_niy, m_njx, m_njy, m_si, m_sj, m_di, m_dj, m_lmin};
+    }
+    double *U() const { return u[cur]; }
+    double *V() const { return v[cur]; }
+    double *P() const { return p[cur]; }
+    double *U1() const { return u[1 - cur]; }
+    double *V1() const { return v[1 - cur]; }
+    double *P1() const { return p[1 - cur]; }
+};
+
+// ------------------------------------------------------------------ launch helpers
+inline dim3 block2d() { return dim3(64, 4, 1); }
+inline dim3 grid2d(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4, 1); }
+
+// stencil.hip
+int launch_eddy_viscosity(Ctx *c);
+int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap);
+int launch_flow_bc(Ctx *c, double *u, double *v, double *p);
+int launch_turb_bc(Ctx *c);
+int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]);
+int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, const double *p);
+int launch_turb_rhs(Ctx *c, double dt);
+int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b);
+int launch_pressure_coeffs(Ctx *c, Level &L);
+int launch_pcorr_bc(Ctx *c);
+int launch_correct(Ctx *c, const double *us, const double *vs, const double *u0, const double *v0,
+                   const double *p0, double *uo, double *vo, double *po, double ru, double rv, double rp);
+int launch_continuity(Ctx *c, const double *u, const double *v, const double *p, double *out);
+int launch_face_flux(Ctx *c, const double *u, const double *v, const double *p, int rc, int use_peff,
+                     double *fi, double *fj);
+int launch_grad(Ctx *c, const double *phi, double *gx, double *gy);
+int launch_advect(Ctx *c, const double *phi, const double *fi, const double *fj, double *out);
+int launch_clip(Ctx *c, double *f, double lo);
+int launch_copy_plane(Ctx *c, const double *src, double *dst);
+int launch_weighted_sum(Ctx *c, const double *f, const double *w, double out[2]);
+int launch_metrics_from_nodes(Ctx *c, const double *xn, const double *yn, int node_pitch);
+int launch_metrics_from_rect(Ctx *c, const double *x1, const double *y1);
+
+// linalg.hip
+int reduce_finish(Ctx *c, int nq, int scal_off);       // partials -> scal[scal_off .. +nq)
+int read_scalars(Ctx *c, int off, int n, double *host);
+int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], int nb,
+                        double tol, int maxiter, int *iters, double relres[2], double rms[2]);
+int build_pressure_hierarchy(Ctx *c);
+int pressure_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres);
+int vcycle(Ctx *c, const double *r, double *z);
+int launch_spmv(Ctx *c, const OpDev &op, const double *x, double *y);
+int time_kernel(Ctx *c, int kernel, int reps, double *avg_us);
+
+// api.hip
+int to_device(Ctx *c, const double *host, double *plane, int kind);
+int from_device(Ctx *c, const double *plane, double *host, int kind);
+
+}  // namespace cfd

@@ -1,0 +1,953 @@
+// Stencil kernels of the SIMPLE/PISO outer step for gfx950 (MI355X).
+//
+// Every kernel is HBM-bound fp64 5-point work (no MFMA): threads sweep rows of the
+// [j][i] planes with i on the 64 lanes of a wavefront so that each wave-instruction
+// touches one contiguous 512-byte run; the vertical neighbours come from the same
+// column of the adjacent rows and are served by L1/L2.  Reductions use wavefront
+// shuffles + one LDS stage per workgroup and a fixed-order second pass (deterministic).
+//
+// Arithmetic order follows the reference expression by expression (file:line cited at
+// each kernel) and the build uses -ffp-contract=off, so interior results agree with the
+// numpy oracle to the last bit except where a reduction order differs.
+#include "internal.h"
+
+namespace cfd {
+
+// ----------------------------------------------------------------------------------
+// small device helpers
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    return v;
+}
+
+// block = 256 threads (64 x 4); returns the block result in thread 0
+__device__ __forceinline__ double block_sum_256(double v) {
+    __shared__ double sm[4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__device__ __forceinline__ double block_min_256(double v) {
+    __shared__ double sm[4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    v = wave_min(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    return fmin(fmin(sm[0], sm[1]), fmin(sm[2], sm[3]));
+}
+
+struct FluxIn {
+    const double *u, *v, *p, *k, *ap;   // k != nullptr: p_eff = p + (2/3) k  (solver.py:427-436)
+    int rc;
+};
+
+__device__ __forceinline__ double peff(const FluxIn &f, size_t c) {
+    return f.k ? f.p[c] + (2.0 / 3.0) * f.k[c] : f.p[c];
+}
+
+// Face flux through the i-face whose right-hand cell has plane index cR
+// (solver.py:455-513 with Rhie-Chow, 516-544 without).
+__device__ __forceinline__ double flux_i(const FluxIn &f, const MeshDev &m, size_t cR, bool lo, bool hi) {
+    const double wr = m.wri[cR], wl = 1.0 - wr;
+    const double ui = wl * f.u[cR - 1] + wr * f.u[cR];
+    const double vi = wl * f.v[cR - 1] + wr * f.v[cR];
+    double fl = ui * m.nix[cR] + vi * m.niy[cR];
+    if (f.rc) {
+        double af = lo ? f.ap[cR] : (hi ? f.ap[cR - 1] : wl * f.ap[cR - 1] + wr * f.ap[cR]);
+        af = af > TINY ? af : TINY;
+        const double s = m.si[cR];
+        fl = fl - (s * s) / af * (peff(f, cR) - peff(f, cR - 1));
+    }
+    return fl;
+}
+__device__ __forceinline__ double flux_j(const FluxIn &f, const MeshDev &m, size_t cN, int pitch, bool lo, bool hi) {
+    const size_t cS = cN - pitch;
+    const double wn = m.wnj[cN], ws = 1.0 - wn;
+    const double uj = ws * f.u[cS] + wn * f.u[cN];
+    const double vj = ws * f.v[cS] + wn * f.v[cN];
+    double fl = uj * m.njx[cN] + vj * m.njy[cN];
+    if (f.rc) {
+        double af = lo ? f.ap[cN] : (hi ? f.ap[cS] : ws * f.ap[cS] + wn * f.ap[cN]);
+        af = af > TINY ? af : TINY;
+        const double s = m.sj[cN];
+        fl = fl - (s * s) / af * (peff(f, cN) - peff(f, cS));
+    }
+    return fl;
+}
+
+// Green-Gauss gradient of a ghosted plane at cell c (solver.py:322-358)
+template <typename F>
+__device__ __forceinline__ void green_gauss(F phi, const MeshDev &m, size_t c, int pitch, double &gx, double &gy) {
+    const double pc = phi(c);
+    double wr = m.wri[c];
+    const double pw = (1.0 - wr) * phi(c - 1) + wr * pc;
+    wr = m.wri[c + 1];
+    const double pe = (1.0 - wr) * pc + wr * phi(c + 1);
+    double wn = m.wnj[c];
+    const double ps = (1.0 - wn) * phi(c - pitch) + wn * pc;
+    wn = m.wnj[c + pitch];
+    const double pn = (1.0 - wn) * pc + wn * phi(c + pitch);
+    const double vol = m.vol[c];
+    gx = (m.nix[c + 1] * pe - m.nix[c] * pw + m.njx[c + pitch] * pn - m.njx[c] * ps) / vol;
+    gy = (m.niy[c + 1] * pe - m.niy[c] * pw + m.njy[c + pitch] * pn - m.njy[c] * ps) / vol;
+}
+
+// first-order upwind divergence (solver.py:649-669)
+__device__ __forceinline__ double upwind(const double *phi, size_t c, int pitch, double fw, double fe, double fs,
+                                         double fn, double vol) {
+    const double pc = phi[c];
+    const double pw = fw >= 0.0 ? phi[c - 1] : pc;
+    const double pe = fe >= 0.0 ? pc : phi[c + 1];
+    const double ps = fs >= 0.0 ? phi[c - pitch] : pc;
+    const double pn = fn >= 0.0 ? pc : phi[c + pitch];
+    const double div = fe * pe - fw * pw + fn * pn - fs * ps;
+    return -div / vol;
+}
+
+// ----------------------------------------------------------------------------------
+// eddy viscosity (turbulence.py:388-394): whole ghosted plane, corners included
+// ----------------------------------------------------------------------------------
+__global__ void k_eddy_viscosity(Geo g, const double *k, const double *om, double *nut, int turbulent) {
+    const int ig = blockIdx.x * 64 + threadIdx.x, jg = blockIdx.y * 4 + threadIdx.y;
+    if (ig > g.ni + 1 || jg > g.nj + 1) return;
+    const size_t c = g.at(ig, jg);
+    if (!turbulent) {
+        nut[c] = 0.0;
+        return;
+    }
+    const double ks = fmax(k[c], K_FLOOR), os = fmax(om[c], OMEGA_FLOOR);
+    nut[c] = 1.0 * ks / os;
+}
+
+int launch_eddy_viscosity(Ctx *c) {
+    hipLaunchKernelGGL(k_eddy_viscosity, grid2d(c->g.ni + 2, c->g.nj + 2), block2d(), 0, c->stream, c->g, c->k,
+                       c->omega, c->nut, c->turbulent);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// face diffusion conductances + momentum diagonal (solver.py:147-230, 439-452)
+// nu_cell = nu + coef * nu_t.  Writes a_i (west faces + the i_max face), a_j, a_P.
+// ----------------------------------------------------------------------------------
+__global__ void k_diffusion_ap(Geo g, MeshDev m, const double *nut, double nu, double coef, double inv_dt, double *ai,
+                               double *aj, double *ap) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const size_t c = g.cell(i, j);
+    const int P = g.pitch;
+    const double nuP = nu + coef * nut[c];
+    // west
+    double nf = nuP;
+    if (i > 0) {
+        const double wr = m.wri[c];
+        nf = (1.0 - wr) * (nu + coef * nut[c - 1]) + wr * nuP;
+    }
+    const double aw = nf * m.si[c] / m.di[c];
+    ai[c] = aw;
+    // east
+    nf = nuP;
+    if (i < g.ni - 1) {
+        const double wr = m.wri[c + 1];
+        nf = (1.0 - wr) * nuP + wr * (nu + coef * nut[c + 1]);
+    }
+    const double ae = nf * m.si[c + 1] / m.di[c + 1];
+    if (i == g.ni - 1) ai[c + 1] = ae;
+    // south
+    nf = nuP;
+    if (j > 0) {
+        const double wn = m.wnj[c];
+        nf = (1.0 - wn) * (nu + coef * nut[c - P]) + wn * nuP;
+    }
+    const double as = nf * m.sj[c] / m.dj[c];
+    aj[c] = as;
+    // north
+    nf = nuP;
+    if (j < g.nj - 1) {
+        const double wn = m.wnj[c + P];
+        nf = (1.0 - wn) * nuP + wn * (nu + coef * nut[c + P]);
+    }
+    const double an = nf * m.sj[c + P] / m.dj[c + P];
+    if (j == g.nj - 1) aj[c + P] = an;
+    ap[c] = m.vol[c] * inv_dt + aw + ae + as + an;
+}
+
+int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap) {
+    hipLaunchKernelGGL(k_diffusion_ap, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->nut,
+                       c->nu, nut_coef, 1.0 / dt, ai, aj, ap);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// flow boundary conditions (bc.py:259-347).  blockIdx.y = side.  Ghosts depend only on
+// interior values, so one launch covers all four sides; the host resolved overlapping
+// segments (last one wins) into per-index tables.
+// ----------------------------------------------------------------------------------
+struct WrapList {
+    double *p[8];
+    int n;
+};
+
+__global__ void k_flow_bc(Geo g, FlowBCDev bc, double *u, double *v, double *p, WrapList wl, int wrap_p_i,
+                          int wrap_p_j) {
+    const int side = blockIdx.y;
+    const int n = (side < 2) ? g.nj : g.ni;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const FlowBCSide &s = bc.side[side];
+    if (s.n != n) return;   // table not set
+    size_t cin, cgh, cop;    // interior cell, its ghost, the interior cell on the opposite side
+    if (side == CFD_SIDE_IMIN) {
+        cin = g.at(1, t + 1); cgh = g.at(0, t + 1); cop = g.at(g.ni, t + 1);
+    } else if (side == CFD_SIDE_IMAX) {
+        cin = g.at(g.ni, t + 1); cgh = g.at(g.ni + 1, t + 1); cop = g.at(1, t + 1);
+    } else if (side == CFD_SIDE_JMIN) {
+        cin = g.at(t + 1, 1); cgh = g.at(t + 1, 0); cop = g.at(t + 1, g.nj);
+    } else {
+        cin = g.at(t + 1, g.nj); cgh = g.at(t + 1, g.nj + 1); cop = g.at(t + 1, 1);
+    }
+    const int kuv = s.kind_uv[t], kp = s.kind_p[t];
+    if (kuv == CFD_BC_PERIODIC) {
+        u[cgh] = u[cop];
+        v[cgh] = v[cop];
+        for (int q = 0; q < wl.n; ++q) wl.p[q][cgh] = wl.p[q][cop];
+    } else if (kuv == CFD_BC_AFFINE) {
+        u[cgh] = s.ua[t] * u[cin] + s.ub[t];
+        v[cgh] = s.va[t] * v[cin] + s.vb[t];
+    } else if (kuv == CFD_BC_SYMMETRY) {
+        const double up = u[cin], vp = v[cin], nx = s.nx[t], ny = s.ny[t];
+        const double un = up * nx + vp * ny;
+        u[cgh] = up - 2.0 * un * nx;
+        v[cgh] = vp - 2.0 * un * ny;
+    }
+    if (kp == CFD_BC_PERIODIC) {
+        const bool wrap = (side < 2) ? wrap_p_i : wrap_p_j;
+        if (wrap) p[cgh] = p[cop];
+    } else if (kp == CFD_BC_AFFINE) {
+        p[cgh] = s.pa[t] * p[cin] + s.pb[t];
+    }
+}
+
+int launch_flow_bc(Ctx *c, double *u, double *v, double *p) {
+    WrapList wl{};
+    wl.n = 0;
+    if (c->turbulent) {
+        wl.p[wl.n++] = c->k;
+        wl.p[wl.n++] = c->omega;
+    }
+    wl.p[wl.n++] = c->nut;
+    const int n = c->g.ni > c->g.nj ? c->g.ni : c->g.nj;
+    hipLaunchKernelGGL(k_flow_bc, dim3((n + 255) / 256, 4, 1), dim3(256, 1, 1), 0, c->stream, c->g, c->fbc, u, v, p, wl,
+                       c->wrap_p_i, c->wrap_p_j);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// k / omega boundary program (turbulence.py:266-341): ops run in list order because a
+// wall op rewrites INTERIOR cells that later ops read at the corners.
+// ----------------------------------------------------------------------------------
+__global__ void k_turb_op(Geo g, int op, int side, int lo, int hi, double a, const double *vals, double *f,
+                          double *f2) {
+    const int t = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > hi) return;
+    if (op == CFD_TOP_WRAP_I) {   // t runs over j
+        f[g.at(0, t + 1)] = f[g.at(g.ni, t + 1)];
+        f[g.at(g.ni + 1, t + 1)] = f[g.at(1, t + 1)];
+        f2[g.at(0, t + 1)] = f2[g.at(g.ni, t + 1)];
+        f2[g.at(g.ni + 1, t + 1)] = f2[g.at(1, t + 1)];
+        return;
+    }
+    if (op == CFD_TOP_WRAP_J) {   // t runs over i
+        f[g.at(t + 1, 0)] = f[g.at(t + 1, g.nj)];
+        f[g.at(t + 1, g.nj + 1)] = f[g.at(t + 1, 1)];
+        f2[g.at(t + 1, 0)] = f2[g.at(t + 1, g.nj)];
+        f2[g.at(t + 1, g.nj + 1)] = f2[g.at(t + 1, 1)];
+        return;
+    }
+    size_t cin, cgh;
+    if (side == CFD_SIDE_IMIN) {
+        cin = g.at(1, t + 1); cgh = g.at(0, t + 1);
+    } else if (side == CFD_SIDE_IMAX) {
+        cin = g.at(g.ni, t + 1); cgh = g.at(g.ni + 1, t + 1);
+    } else if (side == CFD_SIDE_JMIN) {
+        cin = g.at(t + 1, 1); cgh = g.at(t + 1, 0);
+    } else {
+        cin = g.at(t + 1, g.nj); cgh = g.at(t + 1, g.nj + 1);
+    }
+    const double val = vals[t - lo];
+    if (op == CFD_TOP_SET_INTERIOR)
+        f[cin] = val;
+    else
+        f[cgh] = a * f[cin] + val;
+}
+
+int launch_turb_bc(Ctx *c) {
+    for (const cfd_turb_op &o : c->turb_ops) {
+        double *f = (o.field == CFD_F_K) ? c->k : c->omega;
+        int lo = o.lo, hi = o.hi;
+        if (o.op == CFD_TOP_WRAP_I) { lo = 0; hi = c->g.nj - 1; }
+        if (o.op == CFD_TOP_WRAP_J) { lo = 0; hi = c->g.ni - 1; }
+        const int n = hi - lo + 1;
+        if (n <= 0) continue;
+        hipLaunchKernelGGL(k_turb_op, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->g, o.op, o.side, lo, hi, o.a,
+                           c->turb_vals + o.value_off, f, c->omega);
+        CFD_HIP(hipGetLastError());
+    }
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// adaptive time step (solver.py:547-582): two global minima in one pass
+// ----------------------------------------------------------------------------------
+__global__ void k_dt(Geo g, MeshDev m, const double *u, const double *v, const double *nut, double nu, int use_cfl,
+                     double cfl, int use_diff, double cfl_diff, double *partials, int tiles_x, int tiles) {
+    double madv = INFINITY, mdif = INFINITY;
+    FluxIn f{u, v, nullptr, nullptr, nullptr, 0};
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int i = (tile % tiles_x) * 64 + threadIdx.x, j = (tile / tiles_x) * 4 + threadIdx.y;
+        if (i >= g.ni || j >= g.nj) continue;
+        const size_t c = g.cell(i, j);
+        if (use_cfl) {
+            const double fw = flux_i(f, m, c, false, false), fe = flux_i(f, m, c + 1, false, false);
+            const double fs = flux_j(f, m, c, g.pitch, false, false), fn = flux_j(f, m, c + g.pitch, g.pitch, false, false);
+            const double tot = fabs(fw) + fabs(fe) + fabs(fs) + fabs(fn);
+            const double safe = tot > TINY ? tot : TINY;
+            madv = fmin(madv, cfl * m.vol[c] / safe);
+        }
+        if (use_diff) {
+            const double ne = nu + nut[c];
+            const double ns = ne > 0.0 ? ne : TINY;
+            const double l = m.lmin[c];
+            mdif = fmin(mdif, cfl_diff * (l * l) / ns);
+        }
+    }
+    madv = block_min_256(madv);
+    mdif = block_min_256(mdif);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        partials[blockIdx.x] = madv;
+        partials[MAX_PARTIALS + blockIdx.x] = mdif;
+    }
+}
+
+__global__ void k_min_finish(const double *partials, int n, int nq, double *out) {
+    __shared__ double sm[256];
+    for (int q = 0; q < nq; ++q) {
+        double v = INFINITY;
+        for (int t = threadIdx.x; t < n; t += 256) v = fmin(v, partials[q * MAX_PARTIALS + t]);
+        sm[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + s]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[q] = sm[0];
+        __syncthreads();
+    }
+}
+
+static inline int tiles_of(const Geo &g, int &tx) {
+    tx = (g.ni + 63) / 64;
+    return tx * ((g.nj + 3) / 4);
+}
+static inline int red_blocks(int tiles) { return tiles < 2048 ? tiles : 2048; }
+
+int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]) {
+    int tx;
+    const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
+    hipLaunchKernelGGL(k_dt, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), c->U(), c->V(), c->nut, c->nu, use_cfl,
+                       cfl, use_cfl_diff, cfl_diff, c->partials, tx, tiles);
+    CFD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials, nb, 2, c->scal);
+    CFD_HIP(hipGetLastError());
+    return read_scalars(c, 0, 2, out);
+}
+
+// ----------------------------------------------------------------------------------
+// momentum right-hand sides (solver.py:672-691 advective RHS, 868-876 sources,
+// 723-730 transient + boundary terms), fused: nothing but b_u, b_v is written.
+// kgrad != nullptr adds grad(2/3 k) to grad p (solver.py:871-872, 1621-1626).
+// ----------------------------------------------------------------------------------
+__global__ void k_momentum_rhs(Geo g, MeshDev m, FluxIn f, const double *kgrad, const double *ai, const double *aj,
+                               double inv_dt, double force_u, double force_v, int per_i, int per_j, double *bu,
+                               double *bv) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
+    const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+    const double vol = m.vol[c];
+    const double advu = upwind(f.u, c, P, fw, fe, fs, fn, vol);
+    const double advv = upwind(f.v, c, P, fw, fe, fs, fn, vol);
+    double gx, gy;
+    const double *pp = f.p;
+    green_gauss([pp](size_t q) { return pp[q]; }, m, c, P, gx, gy);
+    if (kgrad) {
+        double kx, ky;
+        green_gauss([kgrad](size_t q) { return (2.0 / 3.0) * kgrad[q]; }, m, c, P, kx, ky);
+        gx = gx + kx;
+        gy = gy + ky;
+    }
+    const double su = advu - gx + force_u, sv = advv - gy + force_v;
+    double b_u = vol * inv_dt * f.u[c] + vol * su;
+    double b_v = vol * inv_dt * f.v[c] + vol * sv;
+    if (!per_i) {
+        if (i == 0) { b_u += ai[c] * f.u[c - 1]; b_v += ai[c] * f.v[c - 1]; }
+        if (i == g.ni - 1) { b_u += ai[c + 1] * f.u[c + 1]; b_v += ai[c + 1] * f.v[c + 1]; }
+    }
+    if (!per_j) {
+        if (j == 0) { b_u += aj[c] * f.u[c - P]; b_v += aj[c] * f.v[c - P]; }
+        if (j == g.nj - 1) { b_u += aj[c + P] * f.u[c + P]; b_v += aj[c + P] * f.v[c + P]; }
+    }
+    bu[c] = b_u;
+    bv[c] = b_v;
+}
+
+int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, const double *p) {
+    // the predictor's Rhie-Chow flux uses p_field = fields["p"] (solver.py:1602-1607);
+    // the 2/3 k term enters through the gradient only.
+    FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
+    hipLaunchKernelGGL(k_momentum_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f,
+                       c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j,
+                       c->bu, c->bv);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// k / omega right-hand sides (solver.py:1109-1136, turbulence.py:427-444).  The flux uses
+// p_eff = p + 2/3 k and the momentum a_P; boundary terms use the transport conductances.
+// ----------------------------------------------------------------------------------
+__global__ void k_turb_rhs(Geo g, MeshDev m, FluxIn f, const double *om, const double *nut, const double *ti,
+                           const double *tj, double inv_dt, int per_i, int per_j, double *bk, double *bw) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
+    const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+    const double vol = m.vol[c];
+    const double *k = f.k;
+    const double advk = upwind(k, c, P, fw, fe, fs, fn, vol);
+    const double advw = upwind(om, c, P, fw, fe, fs, fn, vol);
+    double ux, uy, vx, vy;
+    const double *uu = f.u, *vv = f.v;
+    green_gauss([uu](size_t q) { return uu[q]; }, m, c, P, ux, uy);
+    green_gauss([vv](size_t q) { return vv[q]; }, m, c, P, vx, vy);
+    const double s2 = 2.0 * (ux * ux) + 2.0 * (vy * vy) + (uy + vx) * (uy + vx);
+    const double ks = fmax(k[c], K_FLOOR), os = fmax(om[c], OMEGA_FLOOR);
+    const double srck = nut[c] * s2 - 0.09 * ks * os;
+    const double srcw = (5.0 / 9.0) * s2 - (3.0 / 40.0) * (os * os);
+    double b_k = vol * inv_dt * k[c] + vol * (advk + srck);
+    double b_w = vol * inv_dt * om[c] + vol * (advw + srcw);
+    if (!per_i) {
+        if (i == 0) { b_k += ti[c] * k[c - 1]; b_w += ti[c] * om[c - 1]; }
+        if (i == g.ni - 1) { b_k += ti[c + 1] * k[c + 1]; b_w += ti[c + 1] * om[c + 1]; }
+    }
+    if (!per_j) {
+        if (j == 0) { b_k += tj[c] * k[c - P]; b_w += tj[c] * om[c - P]; }
+        if (j == g.nj - 1) { b_k += tj[c + P] * k[c + P]; b_w += tj[c + P] * om[c + P]; }
+    }
+    bk[c] = b_k;
+    bw[c] = b_w;
+}
+
+int launch_turb_rhs(Ctx *c, double dt) {
+    FluxIn f{c->U(), c->V(), c->P(), c->k, c->ap, c->rhie_chow};
+    hipLaunchKernelGGL(k_turb_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, c->omega,
+                       c->nut, c->ti, c->tj, 1.0 / dt, c->per_i, c->per_j, c->bu, c->bv);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// pressure-correction right-hand side (solver.py:926-933, 985): b = V * (-(div F)/V)
+// ----------------------------------------------------------------------------------
+__global__ void k_pressure_rhs(Geo g, MeshDev m, FluxIn f, double *b) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
+    const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+    const double vol = m.vol[c];
+    const double div = (fe - fw + fn - fs) / vol;
+    b[c] = vol * (-div);
+}
+
+// symmetric elimination of the reference cell (solver.py:1033-1044):
+// its row becomes D x = D value, its column moves to the right-hand side.
+// pin_coef = couplings of the W/E/S/N neighbours to the reference cell.
+__global__ void k_pin_rhs(Geo g, int pi, int pj, double value, const double *pin_coef, const double *D, int per_i,
+                          int per_j, double *b) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const size_t c = g.cell(pi, pj);
+    b[c] = value * D[c];
+    const size_t P = g.pitch;
+    if (pi > 0) b[c - 1] += pin_coef[0] * value;
+    else if (per_i && g.ni > 1) b[c + (g.ni - 1)] += pin_coef[0] * value;
+    if (pi < g.ni - 1) b[c + 1] += pin_coef[1] * value;
+    else if (per_i && g.ni > 1) b[c - (g.ni - 1)] += pin_coef[1] * value;
+    if (pj > 0) b[c - P] += pin_coef[2] * value;
+    else if (per_j && g.nj > 1) b[c + (size_t)(g.nj - 1) * P] += pin_coef[2] * value;
+    if (pj < g.nj - 1) b[c + P] += pin_coef[3] * value;
+    else if (per_j && g.nj > 1) b[c - (size_t)(g.nj - 1) * P] += pin_coef[3] * value;
+}
+
+int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b) {
+    FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
+    hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
+    CFD_HIP(hipGetLastError());
+    if (!c->has_dirichlet) {
+        const Level &L = c->levels[0];
+        hipLaunchKernelGGL(k_pin_rhs, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->pin_value,
+                           c->scal + 64, L.D, c->pp_per_i, c->pp_per_j, b);
+        CFD_HIP(hipGetLastError());
+    }
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// pressure operator planes (solver.py:935-1031): masked face couplings d_f = S^2 / a_f
+// and the diagonal with Neumann (0) / Dirichlet (2 d_f) / periodic (d_f) boundary faces.
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ double dcoef_i(const MeshDev &m, const double *ap, size_t cR, bool lo, bool hi) {
+    const double wr = m.wri[cR], wl = 1.0 - wr;
+    double af = lo ? ap[cR] : (hi ? ap[cR - 1] : wl * ap[cR - 1] + wr * ap[cR]);
+    af = af > TINY ? af : TINY;
+    const double s = m.si[cR];
+    return (s * s) / af;
+}
+__device__ __forceinline__ double dcoef_j(const MeshDev &m, const double *ap, size_t cN, int P, bool lo, bool hi) {
+    const double wn = m.wnj[cN], ws = 1.0 - wn;
+    double af = lo ? ap[cN] : (hi ? ap[cN - P] : ws * ap[cN - P] + wn * ap[cN]);
+    af = af > TINY ? af : TINY;
+    const double s = m.sj[cN];
+    return (s * s) / af;
+}
+
+struct PMasks {
+    const int32_t *m[4];
+};
+
+__global__ void k_pressure_coeffs(Geo g, MeshDev m, const double *ap, PMasks pm, int per_i, int per_j, double *ci,
+                                  double *cj, double *D) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    const double dw = dcoef_i(m, ap, c, i == 0, false), de = dcoef_i(m, ap, c + 1, false, i == g.ni - 1);
+    const double ds = dcoef_j(m, ap, c, P, j == 0, false), dn = dcoef_j(m, ap, c + P, P, false, j == g.nj - 1);
+    double aw = dw, ae = de, as = ds, an = dn;
+    if (!per_i) {
+        if (i == 0) aw = (pm.m[0] && pm.m[0][j]) ? 2.0 * dw : 0.0;
+        if (i == g.ni - 1) ae = (pm.m[1] && pm.m[1][j]) ? 2.0 * de : 0.0;
+    }
+    if (!per_j) {
+        if (j == 0) as = (pm.m[2] && pm.m[2][i]) ? 2.0 * ds : 0.0;
+        if (j == g.nj - 1) an = (pm.m[3] && pm.m[3][i]) ? 2.0 * dn : 0.0;
+    }
+    D[c] = aw + ae + as + an;
+    // face planes keep the boundary-face value too (2 d_f Dirichlet / 0 Neumann): the
+    // operator treats x outside the domain as 0 unless the axis is periodic.
+    ci[c] = aw;
+    if (i == g.ni - 1) ci[c + 1] = ae;
+    cj[c] = as;
+    if (j == g.nj - 1) cj[c + P] = an;
+}
+
+// detach the reference cell: remember the neighbours' couplings to it, then zero them
+__global__ void k_pin_operator(Geo g, int pi, int pj, int per_i, int per_j, double *ci, double *cj, double *pin_coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const size_t c = g.cell(pi, pj);
+    const size_t P = g.pitch;
+    const size_t fw = c, fe = c + 1, fs = c, fn = c + P;
+    // the periodic seam stores one physical face twice (face 0 and face N)
+    const size_t fw2 = c + g.ni, fe2 = c - (g.ni - 1), fs2 = c + (size_t)g.nj * P, fn2 = c - (size_t)(g.nj - 1) * P;
+    pin_coef[0] = (pi > 0) ? ci[fw] : (per_i ? ci[fw2] : 0.0);
+    pin_coef[1] = (pi < g.ni - 1) ? ci[fe] : (per_i ? ci[fe2] : 0.0);
+    pin_coef[2] = (pj > 0) ? cj[fs] : (per_j ? cj[fs2] : 0.0);
+    pin_coef[3] = (pj < g.nj - 1) ? cj[fn] : (per_j ? cj[fn2] : 0.0);
+    ci[fw] = 0.0; ci[fe] = 0.0; cj[fs] = 0.0; cj[fn] = 0.0;
+    if (per_i && pi == 0) ci[fw2] = 0.0;
+    if (per_i && pi == g.ni - 1) ci[fe2] = 0.0;
+    if (per_j && pj == 0) cj[fs2] = 0.0;
+    if (per_j && pj == g.nj - 1) cj[fn2] = 0.0;
+}
+
+int launch_pressure_coeffs(Ctx *c, Level &L) {
+    PMasks pm{{c->pmask[0], c->pmask[1], c->pmask[2], c->pmask[3]}};
+    hipLaunchKernelGGL(k_pressure_coeffs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->ap, pm,
+                       c->pp_per_i, c->pp_per_j, L.ci, L.cj, L.D);
+    CFD_HIP(hipGetLastError());
+    if (!c->has_dirichlet) {
+        hipLaunchKernelGGL(k_pin_operator, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->pp_per_i,
+                           c->pp_per_j, L.ci, L.cj, c->scal + 64);
+        CFD_HIP(hipGetLastError());
+    }
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// p' ghost cells (solver.py:279-319)
+// ----------------------------------------------------------------------------------
+__global__ void k_pcorr_bc(Geo g, PMasks pm, int per_i, int per_j, double *pc) {
+    const int side = blockIdx.y;
+    const int n = (side < 2) ? g.nj : g.ni;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    size_t cin, cgh, cop;
+    if (side == CFD_SIDE_IMIN) {
+        cin = g.at(1, t + 1); cgh = g.at(0, t + 1); cop = g.at(g.ni, t + 1);
+    } else if (side == CFD_SIDE_IMAX) {
+        cin = g.at(g.ni, t + 1); cgh = g.at(g.ni + 1, t + 1); cop = g.at(1, t + 1);
+    } else if (side == CFD_SIDE_JMIN) {
+        cin = g.at(t + 1, 1); cgh = g.at(t + 1, 0); cop = g.at(t + 1, g.nj);
+    } else {
+        cin = g.at(t + 1, g.nj); cgh = g.at(t + 1, g.nj + 1); cop = g.at(t + 1, 1);
+    }
+    const bool per = (side < 2) ? per_i : per_j;
+    if (per) {
+        pc[cgh] = pc[cop];
+    } else {
+        const bool dir = pm.m[side] && pm.m[side][t];
+        pc[cgh] = dir ? -pc[cin] : pc[cin];
+    }
+}
+
+int launch_pcorr_bc(Ctx *c) {
+    PMasks pm{{c->pmask[0], c->pmask[1], c->pmask[2], c->pmask[3]}};
+    const int n = c->g.ni > c->g.nj ? c->g.ni : c->g.nj;
+    hipLaunchKernelGGL(k_pcorr_bc, dim3((n + 255) / 256, 4, 1), dim3(256), 0, c->stream, c->g, pm, c->pp_per_i,
+                       c->pp_per_j, c->pcorr);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// velocity / pressure correction with under-relaxation (solver.py:1056-1087)
+// ----------------------------------------------------------------------------------
+__global__ void k_correct(Geo g, MeshDev m, const double *pc, const double *ap, const double *us, const double *vs,
+                          const double *u0, const double *v0, const double *p0, double *uo, double *vo, double *po,
+                          double ru, double rv, double rp) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const size_t c = g.cell(i, j);
+    double gx, gy;
+    green_gauss([pc](size_t q) { return pc[q]; }, m, c, g.pitch, gx, gy);
+    const double d = m.vol[c] / ap[c];
+    const double uc = us[c] - d * gx, vc = vs[c] - d * gy;
+    const double a = u0[c], b = v0[c];
+    uo[c] = a + ru * (uc - a);
+    vo[c] = b + rv * (vc - b);
+    po[c] = p0[c] + rp * pc[c];
+}
+
+int launch_correct(Ctx *c, const double *us, const double *vs, const double *u0, const double *v0, const double *p0,
+                   double *uo, double *vo, double *po, double ru, double rv, double rp) {
+    hipLaunchKernelGGL(k_correct, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->pcorr, c->ap,
+                       us, vs, u0, v0, p0, uo, vo, po, ru, rv, rp);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// continuity residual (solver.py:1205-1215): sqrt(mean(((div F)/V)^2))
+// ----------------------------------------------------------------------------------
+__global__ void k_continuity(Geo g, MeshDev m, FluxIn f, double *partials, int tiles_x, int tiles) {
+    double acc = 0.0;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int i = (tile % tiles_x) * 64 + threadIdx.x, j = (tile / tiles_x) * 4 + threadIdx.y;
+        if (i >= g.ni || j >= g.nj) continue;
+        const int P = g.pitch;
+        const size_t c = g.cell(i, j);
+        const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
+        const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+        const double div = (fe - fw + fn - fs) / m.vol[c];
+        acc += div * div;
+    }
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = acc;
+}
+
+int launch_continuity(Ctx *c, const double *u, const double *v, const double *p, double *out) {
+    int tx;
+    const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
+    FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
+    hipLaunchKernelGGL(k_continuity, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), f, c->partials, tx, tiles);
+    CFD_HIP(hipGetLastError());
+    c->n_red_blocks = nb;
+    CFD_TRY(reduce_finish(c, 1, 0));
+    double s;
+    CFD_TRY(read_scalars(c, 0, 1, &s));
+    *out = sqrt(s / ((double)c->g.ni * (double)c->g.nj));
+    return CFD_OK;
+}
+
+// volume-weighted sum: out = {sum f V, sum V}  (post_processing.py:602-610)
+__global__ void k_weighted_sum(Geo g, const double *f, const double *w, double *partials, int tiles_x, int tiles) {
+    double a = 0.0, b = 0.0;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int i = (tile % tiles_x) * 64 + threadIdx.x, j = (tile / tiles_x) * 4 + threadIdx.y;
+        if (i >= g.ni || j >= g.nj) continue;
+        const size_t c = g.cell(i, j);
+        a += f[c] * w[c];
+        b += w[c];
+    }
+    a = block_sum_256(a);
+    b = block_sum_256(b);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        partials[blockIdx.x] = a;
+        partials[MAX_PARTIALS + blockIdx.x] = b;
+    }
+}
+
+int launch_weighted_sum(Ctx *c, const double *f, const double *w, double out[2]) {
+    int tx;
+    const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
+    hipLaunchKernelGGL(k_weighted_sum, dim3(nb), block2d(), 0, c->stream, c->g, f, w, c->partials, tx, tiles);
+    CFD_HIP(hipGetLastError());
+    c->n_red_blocks = nb;
+    CFD_TRY(reduce_finish(c, 2, 0));
+    return read_scalars(c, 0, 2, out);
+}
+
+// ----------------------------------------------------------------------------------
+// materialising variants for the fine-grained API (face fluxes, gradient, advection)
+// ----------------------------------------------------------------------------------
+__global__ void k_face_flux(Geo g, MeshDev m, FluxIn f, double *fi, double *fj) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    fi[c] = flux_i(f, m, c, i == 0, false);
+    if (i == g.ni - 1) fi[c + 1] = flux_i(f, m, c + 1, false, true);
+    fj[c] = flux_j(f, m, c, P, j == 0, false);
+    if (j == g.nj - 1) fj[c + P] = flux_j(f, m, c + P, P, false, true);
+}
+
+int launch_face_flux(Ctx *c, const double *u, const double *v, const double *p, int rc, int use_peff, double *fi,
+                     double *fj) {
+    FluxIn f{u, v, p, use_peff ? c->k : nullptr, c->ap, rc};
+    hipLaunchKernelGGL(k_face_flux, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, fi, fj);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+__global__ void k_grad(Geo g, MeshDev m, const double *phi, double *gxo, double *gyo) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const size_t c = g.cell(i, j);
+    double gx, gy;
+    green_gauss([phi](size_t q) { return phi[q]; }, m, c, g.pitch, gx, gy);
+    gxo[c] = gx;
+    gyo[c] = gy;
+}
+
+int launch_grad(Ctx *c, const double *phi, double *gx, double *gy) {
+    hipLaunchKernelGGL(k_grad, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), phi, gx, gy);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+__global__ void k_advect(Geo g, const double *vol, const double *phi, const double *fi, const double *fj, double *out) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const size_t c = g.cell(i, j);
+    out[c] = upwind(phi, c, g.pitch, fi[c], fi[c + 1], fj[c], fj[c + g.pitch], vol[c]);
+}
+
+int launch_advect(Ctx *c, const double *phi, const double *fi, const double *fj, double *out) {
+    hipLaunchKernelGGL(k_advect, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->m_vol, phi, fi, fj, out);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// whole ghosted plane: f = max(f, lo)  (solver.py:1150-1151)
+__global__ void k_clip(Geo g, double *f, double lo) {
+    const int ig = blockIdx.x * 64 + threadIdx.x, jg = blockIdx.y * 4 + threadIdx.y;
+    if (ig > g.ni + 1 || jg > g.nj + 1) return;
+    const size_t c = g.at(ig, jg);
+    f[c] = fmax(f[c], lo);
+}
+
+int launch_clip(Ctx *c, double *f, double lo) {
+    hipLaunchKernelGGL(k_clip, grid2d(c->g.ni + 2, c->g.nj + 2), block2d(), 0, c->stream, c->g, f, lo);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+int launch_copy_plane(Ctx *c, const double *src, double *dst) {
+    CFD_HIP(hipMemcpyAsync(dst, src, c->g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
+// metric planes from node coordinates on the device (mesh.py:186-399).  One thread per
+// cell writes its own cell quantities and its west / south face quantities; the last
+// column / row also writes the i_max / j_max boundary faces.
+// ----------------------------------------------------------------------------------
+struct Pt {
+    double x, y;
+};
+struct MeshOut {
+    double *vol, *wri, *wnj, *nix, *niy, *njx, *njy, *si, *sj, *di, *dj, *lmin;
+};
+
+template <typename NodeFn>
+__device__ __forceinline__ void cell_centroid(NodeFn nd, int i, int j, double &cx, double &cy, double &vol) {
+    const Pt a = nd(i, j), b = nd(i + 1, j), cc = nd(i + 1, j + 1), d = nd(i, j + 1);
+    const double c0 = a.x * b.y - b.x * a.y;
+    const double c1 = b.x * cc.y - cc.x * b.y;
+    const double c2 = cc.x * d.y - d.x * cc.y;
+    const double c3 = d.x * a.y - a.x * d.y;
+    const double area = 0.5 * (c0 + c1 + c2 + c3);
+    vol = fabs(area);
+    cx = ((a.x + b.x) * c0 + (b.x + cc.x) * c1 + (cc.x + d.x) * c2 + (d.x + a.x) * c3) / (6.0 * area);
+    cy = ((a.y + b.y) * c0 + (b.y + cc.y) * c1 + (cc.y + d.y) * c2 + (d.y + a.y) * c3) / (6.0 * area);
+}
+
+__device__ __forceinline__ double interp_t(double lx, double ly, double rx, double ry, double fx, double fy) {
+    const double dx = rx - lx, dy = ry - ly;
+    double den = dx * dx + dy * dy;
+    den = den > 1.0e-14 ? den : 1.0;
+    double t = ((fx - lx) * dx + (fy - ly) * dy) / den;
+    t = fmin(fmax(t, 0.0), 1.0);
+    return t;
+}
+
+template <typename NodeFn>
+__device__ void metrics_cell(Geo g, NodeFn nd, MeshOut o, int i, int j) {
+    const size_t c = g.cell(i, j);
+    const int P = g.pitch;
+    double cx, cy, vol;
+    cell_centroid(nd, i, j, cx, cy, vol);
+    o.vol[c] = vol;
+    const Pt a = nd(i, j), b = nd(i + 1, j), cc = nd(i + 1, j + 1), d = nd(i, j + 1);
+    const double elx = b.x - a.x, ely = b.y - a.y;       // i-edge, south
+    const double ehx = cc.x - d.x, ehy = cc.y - d.y;     // i-edge, north
+    const double ewx = d.x - a.x, ewy = d.y - a.y;       // j-edge, west
+    const double eex = cc.x - b.x, eey = cc.y - b.y;     // j-edge, east
+    const double spi = 0.5 * (hypot(elx, ely) + hypot(ehx, ehy));
+    const double spj = 0.5 * (hypot(ewx, ewy) + hypot(eex, eey));
+    o.lmin[c] = fmin(spi, spj);
+    // ---- west face
+    {
+        double nx = ewy, ny = -ewx;
+        const double ax = 0.5 * (elx + ehx), ay = 0.5 * (ely + ehy);
+        if (nx * ax + ny * ay < 0.0) { nx = -nx; ny = -ny; }
+        o.nix[c] = nx; o.niy[c] = ny;
+        const double s = hypot(nx, ny);
+        o.si[c] = s;
+        const double sn = s > 1.0e-14 ? s : 1.0;
+        const double ux = nx / sn, uy = ny / sn;
+        const double fx = 0.5 * (a.x + d.x), fy = 0.5 * (a.y + d.y);
+        double dd, wr = 0.5;
+        if (i == 0) {
+            dd = 2.0 * fabs((cx - fx) * ux + (cy - fy) * uy);
+        } else {
+            double lx, ly, lv;
+            cell_centroid(nd, i - 1, j, lx, ly, lv);
+            wr = interp_t(lx, ly, cx, cy, fx, fy);
+            dd = fabs((cx - lx) * ux + (cy - ly) * uy);
+        }
+        o.wri[c] = wr;
+        o.di[c] = dd > 1.0e-14 ? dd : 1.0e-14;
+    }
+    // ---- i_max boundary face
+    if (i == g.ni - 1) {
+        double nx = eey, ny = -eex;
+        const double fx = 0.5 * (b.x + cc.x), fy = 0.5 * (b.y + cc.y);
+        if (nx * (fx - cx) + ny * (fy - cy) < 0.0) { nx = -nx; ny = -ny; }
+        o.nix[c + 1] = nx; o.niy[c + 1] = ny;
+        const double s = hypot(nx, ny);
+        o.si[c + 1] = s;
+        const double sn = s > 1.0e-14 ? s : 1.0;
+        const double dd = 2.0 * fabs((cx - fx) * (nx / sn) + (cy - fy) * (ny / sn));
+        o.wri[c + 1] = 0.5;
+        o.di[c + 1] = dd > 1.0e-14 ? dd : 1.0e-14;
+    }
+    // ---- south face
+    {
+        double nx = -ely, ny = elx;
+        const double ax = 0.5 * (ewx + eex), ay = 0.5 * (ewy + eey);
+        if (nx * ax + ny * ay < 0.0) { nx = -nx; ny = -ny; }
+        o.njx[c] = nx; o.njy[c] = ny;
+        const double s = hypot(nx, ny);
+        o.sj[c] = s;
+        const double sn = s > 1.0e-14 ? s : 1.0;
+        const double ux = nx / sn, uy = ny / sn;
+        const double fx = 0.5 * (a.x + b.x), fy = 0.5 * (a.y + b.y);
+        double dd, wn = 0.5;
+        if (j == 0) {
+            dd = 2.0 * fabs((cx - fx) * ux + (cy - fy) * uy);
+        } else {
+            double lx, ly, lv;
+            cell_centroid(nd, i, j - 1, lx, ly, lv);
+            wn = interp_t(lx, ly, cx, cy, fx, fy);
+            dd = fabs((cx - lx) * ux + (cy - ly) * uy);
+        }
+        o.wnj[c] = wn;
+        o.dj[c] = dd > 1.0e-14 ? dd : 1.0e-14;
+    }
+    // ---- j_max boundary face
+    if (j == g.nj - 1) {
+        double nx = -ehy, ny = ehx;
+        const double fx = 0.5 * (d.x + cc.x), fy = 0.5 * (d.y + cc.y);
+        if (nx * (fx - cx) + ny * (fy - cy) < 0.0) { nx = -nx; ny = -ny; }
+        o.njx[c + P] = nx; o.njy[c + P] = ny;
+        const double s = hypot(nx, ny);
+        o.sj[c + P] = s;
+        const double sn = s > 1.0e-14 ? s : 1.0;
+        const double dd = 2.0 * fabs((cx - fx) * (nx / sn) + (cy - fy) * (ny / sn));
+        o.wnj[c + P] = 0.5;
+        o.dj[c + P] = dd > 1.0e-14 ? dd : 1.0e-14;
+    }
+}
+
+// nodes as two planes [jn][in] with pitch np
+__global__ void k_metrics_nodes(Geo g, const double *xn, const double *yn, int np, MeshOut o) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    auto nd = [xn, yn, np](int a, int b) { return Pt{xn[(size_t)b * np + a], yn[(size_t)b * np + a]}; };
+    metrics_cell(g, nd, o, i, j);
+}
+// rectangular mesh: nodes are the tensor product of two 1-D arrays (mesh.py:82-87)
+__global__ void k_metrics_rect(Geo g, const double *x1, const double *y1, MeshOut o) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    auto nd = [x1, y1](int a, int b) { return Pt{x1[a], y1[b]}; };
+    metrics_cell(g, nd, o, i, j);
+}
+
+static MeshOut mesh_out(Ctx *c) {
+    return MeshOut{c->m_vol, c->m_wri, c->m_wnj, c->m_nix, c->m_niy, c->m_njx, c->m_njy,
+                   c->m_si,  c->m_sj,  c->m_di,  c->m_dj,  c->m_lmin};
+}
+
+int launch_metrics_from_nodes(Ctx *c, const double *xn, const double *yn, int node_pitch) {
+    hipLaunchKernelGGL(k_metrics_nodes, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, xn, yn, node_pitch,
+                       mesh_out(c));
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+int launch_metrics_from_rect(Ctx *c, const double *x1, const double *y1) {
+    hipLaunchKernelGGL(k_metrics_rect, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, x1, y1, mesh_out(c));
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+}  // namespace cfd

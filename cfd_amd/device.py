@@ -1,0 +1,263 @@
+"""Thin object wrapper over the C ABI (include/cfd_hip.h): one Device = one GPU context
+holding every mesh / field plane of one j-slab in HBM."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, dptr, iptr
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Device:
+    def __init__(self, ni, nj, device=0, workspace_ptr=None, workspace_bytes=0):
+        self.lib = _lib.load()
+        self.ni, self.nj = int(ni), int(nj)
+        self._h = C.c_void_p()
+        check(self.lib.cfd_create(C.byref(self._h), self.ni, self.nj, int(device),
+                                  C.c_void_p(workspace_ptr) if workspace_ptr else None,
+                                  int(workspace_bytes)))
+        self.turbulent = False
+
+    def close(self):
+        if self._h:
+            self.lib.cfd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- shapes
+    def shape(self, kind):
+        ni, nj = self.ni, self.nj
+        return {(_lib.KIND_GHOSTED): (ni + 2, nj + 2), (_lib.KIND_CELL): (ni, nj),
+                (_lib.KIND_FACE_I): (ni + 1, nj), (_lib.KIND_FACE_J): (ni, nj + 1)}[kind]
+
+    # ---------------------------------------------------------------- mesh
+    def upload_mesh(self, mesh):
+        wl, wr = np.asarray(mesh["w_left_i"]), np.asarray(mesh["w_right_i"])
+        ws, wn = np.asarray(mesh["w_south_j"]), np.asarray(mesh["w_north_j"])
+        if not (np.array_equal(wl, 1.0 - wr) and np.array_equal(ws, 1.0 - wn)):
+            raise ValueError("mesh interpolation weights are not complementary (w_left != 1 - w_right); "
+                             "regenerate the mesh with precompute_from_nodes")
+        arrs = [_f64(mesh[k]) for k in ("cell_volume", "w_right_i", "w_north_j", "face_normal_i",
+                                        "face_normal_j", "diff_d_i", "diff_d_j", "cell_spacing_i",
+                                        "cell_spacing_j")]
+        if arrs[0].shape != (self.ni, self.nj):
+            raise ValueError(f"mesh is {arrs[0].shape}, context is {(self.ni, self.nj)}")
+        check(self.lib.cfd_upload_mesh(self._h, *[dptr(a) for a in arrs]))
+
+    def mesh_from_nodes(self, node):
+        node = _f64(node)
+        if node.shape != (self.ni + 1, self.nj + 1, 2):
+            raise ValueError("node must have shape (Ni+1, Nj+1, 2)")
+        check(self.lib.cfd_mesh_from_nodes(self._h, dptr(node)))
+
+    def mesh_from_rect(self, x_nodes, y_nodes):
+        x, y = _f64(x_nodes), _f64(y_nodes)
+        if x.shape != (self.ni + 1,) or y.shape != (self.nj + 1,):
+            raise ValueError("node axes must have Ni+1 and Nj+1 entries")
+        check(self.lib.cfd_mesh_from_rect(self._h, dptr(x), dptr(y)))
+
+    MESH_PLANES = ("vol", "wr_i", "wn_j", "nix", "niy", "njx", "njy", "s_i", "s_j", "d_i", "d_j", "lmin")
+    _MESH_KINDS = (1, 2, 3, 2, 2, 3, 3, 2, 3, 2, 3, 1)
+
+    def download_mesh_plane(self, name):
+        pid = self.MESH_PLANES.index(name)
+        out = np.empty(self.shape(self._MESH_KINDS[pid]))
+        check(self.lib.cfd_download_mesh_plane(self._h, pid, dptr(out)))
+        return out
+
+    # ---------------------------------------------------------------- fields
+    def upload(self, field_id, arr, kind=_lib.KIND_GHOSTED):
+        a = _f64(arr)
+        if a.shape != self.shape(kind):
+            raise ValueError(f"Field shape {a.shape} does not match target {self.shape(kind)}.")
+        check(self.lib.cfd_upload_field(self._h, field_id, dptr(a), kind))
+
+    def download(self, field_id, kind=_lib.KIND_GHOSTED, out=None):
+        if out is None:
+            out = np.empty(self.shape(kind))
+        check(self.lib.cfd_download_field(self._h, field_id, dptr(out), kind))
+        return out
+
+    def upload_fields(self, fields):
+        for name, fid in _lib.FIELD_IDS.items():
+            if name in fields and name != "p_corr":
+                self.upload(fid, fields[name])
+
+    def download_fields(self, fields):
+        """Refresh the host dict in place (arrays are caller visible, solver.py:333)."""
+        for name, fid in _lib.FIELD_IDS.items():
+            if name in fields:
+                self.download(fid, out=fields[name])
+        return fields
+
+    # ---------------------------------------------------------------- parameters
+    def set_physics(self, nu, pressure_gradient=(0.0, 0.0), rhie_chow=True, turbulent=False):
+        self.turbulent = bool(turbulent)
+        check(self.lib.cfd_set_physics(self._h, float(nu), float(pressure_gradient[0]),
+                                       float(pressure_gradient[1]), int(bool(rhie_chow)), int(self.turbulent)))
+
+    def set_solver(self, mom_tol=1e-8, mom_maxiter=200, p_tol=1e-8, p_maxiter=200, turb_tol=1e-8,
+                   turb_maxiter=200, freeze_pressure=True):
+        check(self.lib.cfd_set_solver(self._h, float(mom_tol), int(mom_maxiter), float(p_tol), int(p_maxiter),
+                                      float(turb_tol), int(turb_maxiter), int(bool(freeze_pressure))))
+
+    def set_multigrid(self, nu_pre=2, nu_post=2, omega=0.8, coarse_sweeps=40):
+        check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(omega), int(coarse_sweeps), 4))
+
+    def set_turbulence_clip(self, k_min, omega_min):
+        check(self.lib.cfd_set_turbulence_clip(self._h, float(k_min), float(omega_min)))
+
+    # ---------------------------------------------------------------- BC tables
+    def set_boundary(self, tables):
+        """tables: cfd_amd.bc.BoundaryTables"""
+        for side in range(4):
+            t = tables.flow[side]
+            check(self.lib.cfd_set_flow_bc(self._h, side, len(t["kind_uv"]), iptr(t["kind_uv"]), iptr(t["kind_p"]),
+                                           dptr(t["ua"]), dptr(t["ub"]), dptr(t["va"]), dptr(t["vb"]),
+                                           dptr(t["pa"]), dptr(t["pb"]), dptr(t["nx"]), dptr(t["ny"])))
+        check(self.lib.cfd_set_periodicity(self._h, int(tables.per_i), int(tables.per_j),
+                                           int(tables.wrap_p_i), int(tables.wrap_p_j)))
+        m = tables.p_masks
+        check(self.lib.cfd_set_pressure_bc(self._h, iptr(m[0]), iptr(m[1]), iptr(m[2]), iptr(m[3]),
+                                           int(tables.pp_per_i), int(tables.pp_per_j), int(tables.has_dirichlet),
+                                           int(tables.pin[0]), int(tables.pin[1]), float(tables.pin_value)))
+        ops = (_lib.TurbOp * max(1, len(tables.turb_ops)))()
+        for q, o in enumerate(tables.turb_ops):
+            ops[q] = _lib.TurbOp(*o)
+        vals = _f64(tables.turb_values) if len(tables.turb_values) else np.zeros(1)
+        check(self.lib.cfd_set_turb_bc(self._h, len(tables.turb_ops), ops, len(tables.turb_values), dptr(vals)))
+
+    # ---------------------------------------------------------------- the step
+    def apply_flow_bc(self):
+        check(self.lib.cfd_apply_flow_bc(self._h))
+
+    def compute_dt(self, cfl, cfl_diff, dt_min, dt_max):
+        out = np.zeros(3)
+        check(self.lib.cfd_compute_dt(self._h, int(cfl is not None), float(cfl or 0.0),
+                                      int(cfl_diff is not None), float(cfl_diff or 0.0),
+                                      float(dt_min if dt_min is not None else -np.inf),
+                                      int(dt_max is not None), float(dt_max or 0.0), dptr(out)))
+        return float(out[0]), float(out[1]), float(out[2])
+
+    def simple_iter(self, dt, relax_u, relax_v, relax_p):
+        res = np.zeros(3)
+        check(self.lib.cfd_simple_iter(self._h, float(dt), float(relax_u), float(relax_v), float(relax_p), dptr(res)))
+        return float(res[0]), float(res[1]), float(res[2])
+
+    def piso_step(self, dt, n_correctors, relax_u, relax_v, relax_p):
+        res = np.zeros(3)
+        check(self.lib.cfd_piso_step(self._h, float(dt), int(n_correctors), float(relax_u), float(relax_v),
+                                     float(relax_p), dptr(res)))
+        return float(res[0]), float(res[1]), float(res[2])
+
+    def turbulence_step(self, dt):
+        check(self.lib.cfd_turbulence_step(self._h, float(dt)))
+
+    def stats(self):
+        s = _lib.SolveStats()
+        check(self.lib.cfd_get_stats(self._h, C.byref(s)))
+        return {"mom_iters": s.mom_iters, "p_iters": s.p_iters, "k_iters": s.k_iters,
+                "p_solver": "mg-pcg" if s.p_solver == 0 else "mg-bicgstab",
+                "mom_relres": tuple(s.mom_relres), "p_relres": s.p_relres, "k_relres": tuple(s.k_relres)}
+
+    def bulk_velocity(self, field_id=_lib.F_U):
+        out = C.c_double()
+        check(self.lib.cfd_bulk_velocity(self._h, field_id, C.byref(out)))
+        return out.value
+
+    def synchronize(self):
+        check(self.lib.cfd_synchronize(self._h))
+
+    # ---------------------------------------------------------------- fine-grained
+    def eddy_viscosity(self):
+        check(self.lib.cfd_eddy_viscosity(self._h))
+
+    def momentum_diagonal(self, dt, nut_coef=1.0):
+        check(self.lib.cfd_momentum_diagonal(self._h, float(dt), float(nut_coef)))
+
+    def face_flux(self, rhie_chow=True, use_peff=False):
+        fi, fj = np.empty(self.shape(2)), np.empty(self.shape(3))
+        check(self.lib.cfd_face_flux(self._h, int(rhie_chow), int(use_peff), dptr(fi), dptr(fj)))
+        return fi, fj
+
+    def grad(self, field_id):
+        g = np.empty((self.ni, self.nj, 2))
+        check(self.lib.cfd_grad(self._h, field_id, dptr(g)))
+        return g
+
+    def advect(self, field_id, flux_i, flux_j):
+        out = np.empty((self.ni, self.nj))
+        check(self.lib.cfd_advect(self._h, field_id, dptr(_f64(flux_i)), dptr(_f64(flux_j)), dptr(out)))
+        return out
+
+    def momentum_rhs(self, dt):
+        check(self.lib.cfd_momentum_rhs(self._h, float(dt)))
+
+    def momentum_solve(self):
+        res = np.zeros(2)
+        check(self.lib.cfd_momentum_solve(self._h, dptr(res)))
+        return float(res[0]), float(res[1])
+
+    def pressure_solve(self):
+        check(self.lib.cfd_pressure_solve(self._h))
+
+    def pressure_system(self):
+        ci, cj = np.empty(self.shape(2)), np.empty(self.shape(3))
+        d, b = np.empty(self.shape(1)), np.empty(self.shape(1))
+        check(self.lib.cfd_download_pressure_system(self._h, dptr(ci), dptr(cj), dptr(d), dptr(b)))
+        return ci, cj, d, b
+
+    def snapshot(self):
+        check(self.lib.cfd_snapshot(self._h))
+
+    def correct(self, relax_u, relax_v, relax_p):
+        check(self.lib.cfd_correct(self._h, float(relax_u), float(relax_v), float(relax_p)))
+
+    def continuity(self):
+        out = C.c_double()
+        check(self.lib.cfd_continuity(self._h, C.byref(out)))
+        return out.value
+
+    def apply_turb_bc(self):
+        check(self.lib.cfd_apply_turb_bc(self._h))
+
+    def spmv(self, which, x):
+        y = np.empty((self.ni, self.nj))
+        check(self.lib.cfd_spmv(self._h, int(which), dptr(_f64(x)), dptr(y)))
+        return y
+
+    def vcycle(self, r):
+        z = np.empty((self.ni, self.nj))
+        check(self.lib.cfd_vcycle(self._h, dptr(_f64(r)), dptr(z)))
+        return z
+
+    def pressure_krylov(self, b, tol=1e-10, maxiter=200):
+        x = np.empty((self.ni, self.nj))
+        it, rr = C.c_int(), C.c_double()
+        check(self.lib.cfd_pressure_krylov(self._h, dptr(_f64(b)), dptr(x), float(tol), int(maxiter),
+                                           C.byref(it), C.byref(rr)))
+        return x, it.value, rr.value
+
+    def time_kernel(self, kernel, reps=20):
+        out = C.c_double()
+        check(self.lib.cfd_time_kernel(self._h, int(kernel), int(reps), C.byref(out)))
+        return out.value
+
+    def enable_phase_timing(self, on=True):
+        check(self.lib.cfd_enable_phase_timing(self._h, int(on)))
+
+    def phase_times(self, reset=True):
+        out = np.zeros(8)
+        check(self.lib.cfd_phase_times(self._h, dptr(out), int(reset)))
+        return dict(zip(("bc", "adv", "mom", "press", "corr", "cont", "turb", "dt"), out / 1e6))

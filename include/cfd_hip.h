@@ -1,0 +1,234 @@
+/*
+ * cfd_hip.h -- C ABI of the MI355X (gfx950) SIMPLE/PISO hot path.
+ *
+ * The reference (AltoAuto/CFD) has no FFI: its boundary is the Python module API of
+ * "Project 1/solver.py".  The entry points below are what a ctypes binding of that
+ * module binds for the hot path; each one cites the reference routine it replaces
+ * (file:line relative to /root/reference).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative CFD_E_* code on failure; the
+ *     message is available from cfd_last_error() (thread local).
+ *   - host arrays are the reference's numpy layout: C-order float64, shape
+ *     (Ni+2, Nj+2) for ghosted cell fields [i][j] (j contiguous), (Ni+1, Nj) for
+ *     i-face arrays, (Ni, Nj+1) for j-face arrays, (Ni, Nj) for interior arrays.
+ *   - device layout: transposed planes [j][i], i contiguous, one ghost
+ *     layer, row pitch padded to 256 B; j-slabs are contiguous row blocks.
+ *   - one context per GPU / per process; calls on one context must not overlap.
+ */
+#ifndef CFD_HIP_H
+#define CFD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cfd_ctx cfd_ctx;
+
+enum {
+    CFD_OK = 0,
+    CFD_E_ARG = -1,      /* bad argument / shape                                  */
+    CFD_E_HIP = -2,      /* HIP runtime error                                     */
+    CFD_E_STATE = -3,    /* call order violated (mesh / BC not set, ...)          */
+    CFD_E_NOCONV = -4,   /* a linear solve did not reach its tolerance            */
+    CFD_E_NUMERIC = -5   /* non-finite value met                                  */
+};
+
+/* field ids for upload / download (fields dict of solver.py:370-387, turbulence.py:215-259) */
+enum { CFD_F_U = 0, CFD_F_V = 1, CFD_F_P = 2, CFD_F_K = 3, CFD_F_OMEGA = 4, CFD_F_NUT = 5,
+       CFD_F_PCORR = 6, CFD_F_AP = 7, CFD_F_AI = 8, CFD_F_AJ = 9, CFD_F_BU = 10, CFD_F_BV = 11,
+       CFD_F_COUNT = 12 };
+
+/* array kinds (host shapes) */
+enum { CFD_KIND_CELL_GHOSTED = 0, CFD_KIND_CELL = 1, CFD_KIND_FACE_I = 2, CFD_KIND_FACE_J = 3 };
+
+/* boundary sides */
+enum { CFD_SIDE_IMIN = 0, CFD_SIDE_IMAX = 1, CFD_SIDE_JMIN = 2, CFD_SIDE_JMAX = 3 };
+
+/* per-index ghost-cell operation codes of the flow BC table (bc.py:196-347) */
+enum { CFD_BC_NONE = 0, CFD_BC_AFFINE = 1, CFD_BC_SYMMETRY = 2, CFD_BC_PERIODIC = 3 };
+
+/* turbulence BC op codes (turbulence.py:266-341), executed in list order */
+enum { CFD_TOP_WRAP_I = 0, CFD_TOP_WRAP_J = 1, CFD_TOP_SET_INTERIOR = 2, CFD_TOP_AFFINE_GHOST = 3 };
+
+typedef struct cfd_turb_op {
+    int32_t op;          /* CFD_TOP_*                                              */
+    int32_t field;       /* CFD_F_K or CFD_F_OMEGA                                 */
+    int32_t side;        /* CFD_SIDE_*                                             */
+    int32_t lo, hi;      /* inclusive boundary-index range (bc.py:16-35)           */
+    int32_t value_off;   /* offset into the values array (hi-lo+1 doubles)         */
+    double a;            /* ghost = a * phi_P + values[idx]  (AFFINE_GHOST)        */
+} cfd_turb_op;
+
+typedef struct cfd_solve_stats {
+    int32_t mom_iters;       /* BiCGStab iterations of the (u, v) predictor         */
+    int32_t p_iters;         /* Krylov iterations of the last pressure solve        */
+    int32_t k_iters;         /* BiCGStab iterations of the (k, omega) transport     */
+    int32_t p_solver;        /* 0 = MG-PCG, 1 = MG-BiCGStab (asymmetric seam)       */
+    double mom_relres[2];    /* final |r|/|b| of u and v                            */
+    double p_relres;         /* final |r|/|b| of the pressure correction            */
+    double k_relres[2];
+} cfd_solve_stats;
+
+const char *cfd_last_error(void);
+int cfd_version(void);
+
+/* ---- context ------------------------------------------------------------------ */
+/* Replaces the in-process state of solver.run_case (solver.py:1367-1451): all planes
+ * live in HBM.  workspace == NULL: the library hipMallocs cfd_workspace_bytes() itself;
+ * otherwise the caller (e.g. a torch tensor) owns the memory, which lets the host
+ * build zero-copy views for RCCL halo exchange.  device: HIP device ordinal.       */
+size_t cfd_workspace_bytes(int ni, int nj);
+int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes);
+int cfd_destroy(cfd_ctx *ctx);
+int cfd_set_stream(cfd_ctx *ctx, void *hip_stream);
+int cfd_synchronize(cfd_ctx *ctx);
+int cfd_pitch(cfd_ctx *ctx);                       /* row pitch in doubles          */
+/* byte offset of a field plane inside the workspace (for zero-copy host views)     */
+int64_t cfd_field_offset(cfd_ctx *ctx, int field_id);
+
+/* ---- mesh (data contract of mesh.precompute_from_nodes, mesh.py:186-399) -------- */
+/* Host arrays in the reference's .npz layout.  w_left is not passed: the contract has
+ * w_left = 1 - w_right exactly (mesh.py:268-276) and the host wrapper checks it.     */
+int cfd_upload_mesh(cfd_ctx *ctx,
+                    const double *cell_volume,      /* (Ni, Nj)                     */
+                    const double *w_right_i,        /* (Ni+1, Nj)                   */
+                    const double *w_north_j,        /* (Ni, Nj+1)                   */
+                    const double *face_normal_i,    /* (Ni+1, Nj, 2)                */
+                    const double *face_normal_j,    /* (Ni, Nj+1, 2)                */
+                    const double *diff_d_i,         /* (Ni+1, Nj)                   */
+                    const double *diff_d_j,         /* (Ni, Nj+1)                   */
+                    const double *cell_spacing_i,   /* (Ni, Nj)                     */
+                    const double *cell_spacing_j);  /* (Ni, Nj)                     */
+/* Same planes computed on the device from the node coordinates (Ni+1, Nj+1, 2); avoids
+ * the 27-doubles-per-cell host mesh at 8192^2 (mesh.py:186-399).   */
+int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node);
+/* Same, for a rectangular mesh given by its two 1-D node coordinate arrays
+ * (mesh.generate_rect_nodes, mesh.py:82-87) without materialising the node grid.    */
+int cfd_mesh_from_rect(cfd_ctx *ctx, const double *x_nodes, const double *y_nodes);
+/* download one device mesh plane (for parity tests): id 0..11 = vol, wr_i, wn_j, nix,
+ * niy, njx, njy, s_i, s_j, d_i, d_j, lmin; kind as CFD_KIND_*                        */
+int cfd_download_mesh_plane(cfd_ctx *ctx, int plane_id, double *host);
+
+/* ---- fields --------------------------------------------------------------------- */
+/* solver.initialize_fields / load_state / save_fields (solver.py:370-419, 1296-1310)  */
+int cfd_upload_field(cfd_ctx *ctx, int field_id, const double *host, int kind);
+int cfd_download_field(cfd_ctx *ctx, int field_id, double *host, int kind);
+
+/* ---- parameters ----------------------------------------------------------------- */
+/* physics.nu, physics.pressure_gradient, solver.rhie_chow, turbulence on/off
+ * (solver.py:1393-1397, 1529, turbulence.py:215-224)                                 */
+int cfd_set_physics(cfd_ctx *ctx, double nu, double dpdx, double dpdy, int rhie_chow, int turbulent);
+/* solver.momentum / solver.pressure {tol, maxiter} (solver.py:863-864, 919-920);
+ * k/omega transport uses the reference's hard-coded 1e-8 / 200 unless overridden
+ * (solver.py:788-789, 1138-1139).  freeze_pressure = 1 keeps the first pressure
+ * operator of the run (cached pyamg hierarchy, solver.py:821-833).       */
+int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, int p_maxiter,
+                   double turb_tol, int turb_maxiter, int freeze_pressure);
+/* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps            */
+int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int min_size);
+/* turbulence clip after the k/omega solve (solver.py:1147-1151)                       */
+int cfd_set_turbulence_clip(cfd_ctx *ctx, double k_min, double omega_min);
+
+/* ---- boundary conditions --------------------------------------------------------- */
+/* Flow ghost-cell table for one side, resolved per boundary index by the host from
+ * the CONFIG["boundary"] segments (bc.apply_boundary_conditions, bc.py:259-347):
+ *   kind_uv[n], kind_p[n]: CFD_BC_*;  u_g = ua*u_P + ub, v_g = va*v_P + vb,
+ *   p_g = pa*p_P + pb;  symmetry uses the unit normal (nx, ny) (bc.py:241-256).       */
+int cfd_set_flow_bc(cfd_ctx *ctx, int side, int n, const int32_t *kind_uv, const int32_t *kind_p,
+                    const double *ua, const double *ub, const double *va, const double *vb,
+                    const double *pa, const double *pb, const double *nx, const double *ny);
+/* periodicity of the transport systems (bc.get_periodic_pairs, bc.py:72-91) and
+ * whether the periodic wrap also copies p (bc.py:266-286)                             */
+int cfd_set_periodicity(cfd_ctx *ctx, int per_i, int per_j, int wrap_p_i, int wrap_p_j);
+/* pressure-correction BCs: Dirichlet-p masks per side (solver.py:245-276), the
+ * periodicity seen by p' (solver.py:959-966) and the reference cell
+ * (solver.py:1033-1044).  masks may be NULL (all false).                              */
+int cfd_set_pressure_bc(cfd_ctx *ctx, const int32_t *mask_imin, const int32_t *mask_imax,
+                        const int32_t *mask_jmin, const int32_t *mask_jmax,
+                        int per_i, int per_j, int has_dirichlet, int pin_i, int pin_j, double pin_value);
+/* k / omega boundary program (turbulence.apply_bcs, turbulence.py:291-341)             */
+int cfd_set_turb_bc(cfd_ctx *ctx, int n_ops, const cfd_turb_op *ops, int n_values, const double *values);
+
+/* ---- the outer step ---------------------------------------------------------------- */
+/* bc.apply_boundary_conditions on the current u, v, p (+ periodic wrap of k, omega, nu_t) */
+int cfd_apply_flow_bc(cfd_ctx *ctx);
+/* solver.compute_adaptive_dt (solver.py:547-582) with nu_eff = nu + stored (lagged) nu_t
+ * (solver.py:1473-1475).  use_cfl / use_cfl_diff = 0 means "None".  out = {dt, dt_adv,
+ * dt_diff}.  Global min reduction on the device.                                        */
+int cfd_compute_dt(cfd_ctx *ctx, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff,
+                   double dt_min, int use_dt_max, double dt_max, double out[3]);
+/* One SIMPLE inner iteration (solver.py:1591-1681): BCs, snapshot, nu_t, a_P, advective
+ * RHS, momentum predictor, BCs, pressure correction, velocity/pressure correction with
+ * under-relaxation, BCs, continuity residual.  res = {continuity_l2, mom_u_l2, mom_v_l2}. */
+int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, double relax_p,
+                    double res[3]);
+/* One PISO step (solver.py:1494-1589) with n_correctors correctors against the
+ * start-of-step snapshot.                                                */
+int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, double relax_v,
+                  double relax_p, double res[3]);
+/* solver.update_turbulence, k-omega (solver.py:1090-1153)                                */
+int cfd_turbulence_step(cfd_ctx *ctx, double dt);
+int cfd_get_stats(cfd_ctx *ctx, cfd_solve_stats *out);
+/* volume-weighted mean of u or v over the interior (post_processing.py:602-610)          */
+int cfd_bulk_velocity(cfd_ctx *ctx, int field_id, double *out);
+
+/* ---- fine-grained entry points (parity tests; README.md:196-205 function list) ------- */
+/* turbulence.eddy_viscosity, k-omega branch (turbulence.py:388-394): nu_t plane from k, omega */
+int cfd_eddy_viscosity(cfd_ctx *ctx);
+/* solver._diffusion_coefficients + _momentum_diagonal (solver.py:147-230, 439-452):
+ * writes a_i, a_j, a_P planes for nu_eff = nu + nut_coef * nu_t                           */
+int cfd_momentum_diagonal(cfd_ctx *ctx, double dt, double nut_coef);
+/* solver._face_mass_flux / _face_volumetric_flux (solver.py:455-544) from the current
+ * u, v, p (+2/3 k when use_peff) and the a_P plane; host outputs (Ni+1,Nj), (Ni,Nj+1)     */
+int cfd_face_flux(cfd_ctx *ctx, int rhie_chow, int use_peff, double *flux_i, double *flux_j);
+/* solver.grad_scalar / numba_kernels.grad_scalar_numba (solver.py:322-358,
+ * numba_kernels.py:39-83): gradient of a field plane -> host (Ni, Nj, 2)                  */
+int cfd_grad(cfd_ctx *ctx, int field_id, double *grad);
+/* solver.advect_scalar / numba_kernels.advect_scalar_numba (solver.py:649-669,
+ * numba_kernels.py:5-36) with host-supplied face fluxes -> host (Ni, Nj)                   */
+int cfd_advect(cfd_ctx *ctx, int field_id, const double *flux_i, const double *flux_j, double *out);
+/* advective + pressure-gradient momentum RHS planes b_u, b_v (solver.py:672-691, 868-883,
+ * 723-730) for the current fields and the a_P / a_i / a_j planes                           */
+int cfd_momentum_rhs(cfd_ctx *ctx, double dt);
+/* solve the two momentum systems for the stored RHS planes (solver.py:785-818, 885-894)     */
+int cfd_momentum_solve(cfd_ctx *ctx, double res[2]);
+/* pressure-correction system (solver.py:904-1053): RHS from the current fields and solve     */
+int cfd_pressure_solve(cfd_ctx *ctx);
+/* download the assembled pressure operator planes (tests): c_i (Ni+1,Nj), c_j (Ni,Nj+1), diag,
+ * rhs (Ni,Nj)                                                                               */
+int cfd_download_pressure_system(cfd_ctx *ctx, double *c_i, double *c_j, double *diag, double *rhs);
+/* solver.correct_velocity (solver.py:1056-1087) against the snapshot planes                  */
+int cfd_correct(cfd_ctx *ctx, double relax_u, double relax_v, double relax_p);
+int cfd_snapshot(cfd_ctx *ctx);   /* u0, v0, p0 := current (solver.py:1596-1598)              */
+/* solver.continuity_residual (solver.py:1205-1215)                                           */
+int cfd_continuity(cfd_ctx *ctx, double *out);
+/* turbulence.apply_bcs program                                                               */
+int cfd_apply_turb_bc(cfd_ctx *ctx);
+
+/* ---- standalone linear-algebra entry points (tests, roofline micro-benchmarks) ------------ */
+/* y = A x for the momentum operator (which = 0) or the pressure operator (which = 1);
+ * x, y host (Ni, Nj)                                                                         */
+int cfd_spmv(cfd_ctx *ctx, int which, const double *x, double *y);
+/* one multigrid V-cycle z = M r on the pressure operator; host (Ni, Nj)                      */
+int cfd_vcycle(cfd_ctx *ctx, const double *r, double *z);
+/* solve A x = b on the pressure operator with the configured Krylov method; returns iters     */
+int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, int maxiter, int *iters,
+                        double *relres);
+/* timing helpers for bench.py: run `reps` launches of one hot kernel on resident data and
+ * return the average kernel time in microseconds measured with HIP events on the context
+ * stream.  kernel: 0 = pressure SpMV, 1 = Jacobi smoother sweep (finest level),
+ * 2 = momentum RHS, 3 = batched momentum SpMV, 4 = residual+restrict, 5 = continuity        */
+int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us);
+/* accumulated device time per phase since the last reset (HIP events), microseconds:
+ * {bc, adv(rhs), mom, press, corr, cont, turb, dt}                                          */
+int cfd_phase_times(cfd_ctx *ctx, double out[8], int reset);
+int cfd_enable_phase_timing(cfd_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFD_HIP_H */
