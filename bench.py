@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- outer SIMPLE step throughput on MI355X (contract: see task / DESIGN.md).
+
+One "step" = one outer SIMPLE step (exactly `max_iter` inner iterations, continuity_tol = 0)
+of the synthetic periodic channel of SURVEY.md 8(d) on an N x N cell mesh, all planes
+resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus / step time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5            (default size 8192)
+    torchrun ... bench.py --gpus N ...                        (one rank per GPU)
+
+The JSON line also carries
+  roofline     : the multigrid Jacobi smoother sweep on the finest level (the kernel with the
+                 largest share of device time), timed live with HIP-event pairs around every
+                 launch inside the timed steps; achieved = 48 B/cell * Ni*Nj / avg duration
+                 (x, b, c_i, c_j, D read + x' written: 5R + 1W planes; SURVEY.md 8(d) lists 64 B
+                 for five stored coefficients, this build stores three).
+  cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
+                 factor-once LU pressure) timed on this host, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SMOOTHER_BYTES_PER_CELL = 48   # x, b, c_i, c_j, D read + x' written (3 coefficient planes, not the 5 of SURVEY 8(d))
+
+
+def setup_device(n, turbulent, max_iter, tol, device):
+    from cfd_amd import _lib as L
+    from cfd_amd.bc import BoundaryGeometry
+    from cfd_amd.device import Device
+    from cfd_amd.mesh import rect_node_axes
+    from cfd_amd.solver import StepControl, configure_device
+    from cfd_amd.workloads import channel_forced_config, perturbed_parabola_rows
+
+    cfg, mp = channel_forced_config(n, turbulent, max_iter, tol)
+    x, y = rect_node_axes(**mp)
+    dev = Device(n, n, device)
+    dev.mesh_from_rect(x, y)
+    ctl = StepControl(cfg)
+    configure_device(dev, cfg, BoundaryGeometry.from_rect_axes(x, y), cfg["physics"]["nu"], ctl.turb_on)
+    shape = (n + 2, n + 2)
+    f = np.zeros(shape)
+    f[1:-1, 1:-1] = perturbed_parabola_rows(n, y, seed=1234)
+    dev.upload(L.F_U, f)
+    f[:] = 0.0
+    dev.upload(L.F_V, f)
+    dev.upload(L.F_P, f)
+    dev.upload(L.F_NUT, f)
+    if turbulent:
+        f[1:-1, 1:-1] = 1.0e-4
+        dev.upload(L.F_K, f)
+        f[1:-1, 1:-1] = 10.0
+        dev.upload(L.F_OMEGA, f)
+    del f
+    return dev, ctl, cfg
+
+
+def cpu_baseline(n_cpu, steps, max_iter):
+    """Oracle with the reference's solver mix, on the host cores (1 effective thread)."""
+    from cfd_amd.workloads import channel_forced_config
+    from oracle import cfd_oracle as orc
+    cfg, mp = channel_forced_config(n_cpu, False, max_iter, 1e-8)
+    mesh = orc.rect_mesh(**mp)
+    y = mesh["cell_center"][:, :, 1]
+    rng = np.random.default_rng(1234)
+    cfg["initial"]["u"] = (1.0 - (2.0 * y - 1.0) ** 2) + 1.0e-3 * rng.standard_normal(y.shape)
+    stamps = []
+
+    def tick(fields, rec):
+        stamps.append(time.perf_counter())
+
+    cfg["time"]["max_steps"] = steps + 1
+    t0 = time.perf_counter()
+    orc.run_case(cfg, mesh, solver_mode="reference", freeze_pressure=True, on_step=tick)
+    per_step = (stamps[-1] - stamps[0]) / max(1, len(stamps) - 1)   # first step (LU set-up) excluded
+    return {"value": n_cpu * n_cpu / per_step, "unit": "cell-updates/s", "cores": 1,
+            "kind": "port",
+            "sample": f"{n_cpu}x{n_cpu} laminar channel, {steps} timed outer steps x {max_iter} SIMPLE iterations "
+                      f"after 1 warm-up, rtol 1e-8, {per_step:.3f} s/step, host has {os.cpu_count()} cores, "
+                      f"numpy/SuperLU single-threaded; total {time.perf_counter() - t0:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=8192, help="cells per side (per GPU)")
+    ap.add_argument("--turbulent", action="store_true", help="k-omega variant of the workload")
+    ap.add_argument("--max-iter", type=int, default=2)
+    ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--cpu-size", type=int, default=256)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--probe", type=int, default=1, help="kernel id for the live roofline probe")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    from cfd_amd.solver import advance_one_step
+
+    n = args.size
+    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local)
+    step = 0
+    iters = []
+    for _ in range(args.warmup):
+        info = advance_one_step(dev, ctl, step)
+        step += 1
+    dev.synchronize()
+    dev.probe(args.probe)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = advance_one_step(dev, ctl, step)
+        st = dev.stats()
+        iters.append((st["mom_iters"], st["p_iters"], st["k_iters"]))
+        step += 1
+    dev.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_probe, probe_us = dev.probe_read()
+    dev.probe(-1)
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = world * n * n / (elapsed / args.steps)
+
+    out = None
+    if rank == 0:
+        kernel_names = {0: "pressure SpMV (k_cg_q)", 1: "MG Jacobi smoother sweep, finest level (k_mg_jacobi)",
+                        2: "momentum RHS (k_momentum_rhs)", 3: "batched momentum operator (k_bi_apply<2>)",
+                        4: "residual+restrict (k_mg_restrict)"}
+        bytes_per_cell = {0: 40, 1: SMOOTHER_BYTES_PER_CELL, 2: 120, 3: 72, 4: 42}[args.probe]
+        achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": kernel_names.get(args.probe, str(args.probe)),
+                    "avg_us": probe_us, "launches_timed": n_probe, "bytes_per_cell": bytes_per_cell}
+        it = np.array(iters)
+        out = {
+            "metric": "cell-updates/s per outer step", "value": value, "unit": "cell-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {n}x{n} periodic channel with pressure-gradient forcing "
+                                   f"({'k-omega' if args.turbulent else 'laminar'}), SIMPLE max_iter={args.max_iter}, "
+                                   f"continuity_tol=0, cfl=cfl_diff=0.5, dt_max=1e-3, rtol={args.tol:g}",
+                       "cells_per_gpu": n * n,
+                       "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (j-slab exchange not yet in)",
+                       "inner_iterations": args.max_iter,
+                       "mean_momentum_iters": float(it[:, 0].mean()), "mean_pressure_iters": float(it[:, 1].mean()),
+                       "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,
+                       "last_continuity_l2": info["cont"], "last_dt": info["dt"]},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps, args.max_iter)
+        else:
+            out["cpu_baseline"] = None
+    dev.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,8 @@ SIGNATURES = {
     "cfd_vcycle": (C.c_int, [_vp, _dp, _dp]),
     "cfd_pressure_krylov": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_int, C.POINTER(C.c_int), _dp]),
     "cfd_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "cfd_probe": (C.c_int, [_vp, C.c_int]),
+    "cfd_probe_read": (C.c_int, [_vp, C.POINTER(C.c_int), _dp]),
     "cfd_phase_times": (C.c_int, [_vp, _dp, C.c_int]),
     "cfd_enable_phase_timing": (C.c_int, [_vp, C.c_int]),
 }

@@ -256,6 +256,8 @@ int cfd_destroy(cfd_ctx *ctx) {
     Ctx *c = &ctx->c;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->probe_e0) hipEventDestroy(e);
+    for (hipEvent_t e : c->probe_e1) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -541,7 +543,9 @@ static int do_predictor(Ctx *c, double dt, double res[3]) {
         CFD_TRY(launch_eddy_viscosity(c));
         CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
         c->dt_ap = dt;
+        c->probe_begin(2);
         CFD_TRY(launch_momentum_rhs(c, dt, c->U(), c->V(), c->P()));
+        c->probe_end(2);
     }
     {
         Phase ph(c, PH_MOM);
@@ -834,6 +838,37 @@ int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, in
     if (iters) *iters = it;
     if (relres) *relres = rr;
     return from_device(c, c->kry[12], x, CFD_KIND_CELL);
+}
+
+int cfd_probe(cfd_ctx *ctx, int kernel) {
+    CTX(ctx);
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    if (kernel >= 0 && c->probe_e0.empty()) {
+        c->probe_e0.resize(4096);
+        c->probe_e1.resize(4096);
+        for (size_t q = 0; q < c->probe_e0.size(); ++q) {
+            CFD_HIP(hipEventCreate(&c->probe_e0[q]));
+            CFD_HIP(hipEventCreate(&c->probe_e1[q]));
+        }
+    }
+    c->probe_kernel = kernel;
+    c->probe_n = 0;
+    return CFD_OK;
+}
+
+int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us) {
+    CTX(ctx);
+    if (!count || !avg_us) return CFD_E_ARG;
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (int q = 0; q < c->probe_n; ++q) {
+        float ms = 0.f;
+        CFD_HIP(hipEventElapsedTime(&ms, c->probe_e0[q], c->probe_e1[q]));
+        tot += ms;
+    }
+    *count = c->probe_n;
+    *avg_us = c->probe_n ? 1000.0 * tot / c->probe_n : 0.0;
+    return CFD_OK;
 }
 
 int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us) {

@@ -147,6 +147,17 @@ struct Ctx {
     double phase_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
+    // live kernel probe (bench.py): HIP-event pairs around every launch of one kernel id
+    int probe_kernel = -1;
+    std::vector<hipEvent_t> probe_e0, probe_e1;
+    int probe_n = 0;
+    inline void probe_begin(int id) {
+        if (id == probe_kernel && probe_n < (int)probe_e0.size()) (void)hipEventRecord(probe_e0[probe_n], stream);
+    }
+    inline void probe_end(int id) {
+        if (id == probe_kernel && probe_n < (int)probe_e0.size()) { (void)hipEventRecord(probe_e1[probe_n], stream); ++probe_n; }
+    }
+
     MeshDev mesh() const {
         return MeshDev{m_vol, m_wri, m_wnj, m_nix, m_niy, m_njx, m_njy, m_si, m_sj, m_di, m_dj, m_lmin};
     }

@@ -364,8 +364,10 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
     while (n_active > 0 && it < maxiter) {
         const int gen = it & 1;
         hipLaunchKernelGGL((k_bi_p<NB>), grid, blk, 0, st, g, T, S, gen, it == 0, act, cv(r), cv(v), p);
+        if (NB == 2) c->probe_begin(3);
         hipLaunchKernelGGL((k_bi_apply<NB, true, 0>), grid, blk, 0, st, op, T, inv, act, cv(p), cv(p), cv(rh), v,
                            c->partials);
+        if (NB == 2) c->probe_end(3);
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, NB, OFF_OF(sigma[0])));
         hipLaunchKernelGGL((k_bi_s<NB>), grid, blk, 0, st, g, T, S, gen, act, cv(v), r);
@@ -617,14 +619,18 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         const Tiling T = tiling(L.g);
         hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
         for (int s = 1; s < pre; ++s) {
+            if (l == 0) c->probe_begin(1);
             hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
+            if (l == 0) c->probe_end(1);
             std::swap(cur[l], oth[l]);
         }
         const Level &C = c->levels[l + 1];
         int fi, fj;
         factors(L, C, fi, fj);
         const Tiling Tc = tiling(C.g);
+        if (l == 0) c->probe_begin(4);
         hipLaunchKernelGGL(k_mg_restrict, dim3(Tc.blocks), block2d(), 0, st, op, rhs[l], cur[l], C.g, Tc, fi, fj, C.b);
+        if (l == 0) c->probe_end(4);
         CFD_HIP(hipGetLastError());
     }
     {
@@ -653,7 +659,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         factors(L, C, fi, fj);
         hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, C.g, fi, fj, cur[l + 1], cur[l]);
         for (int s = 0; s < post; ++s) {
+            if (l == 0) c->probe_begin(1);
             hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
+            if (l == 0) c->probe_end(1);
             std::swap(cur[l], oth[l]);
         }
         CFD_HIP(hipGetLastError());
@@ -759,7 +767,9 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rz[gen])));
         hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);
+        c->probe_begin(0);
         hipLaunchKernelGGL(k_cg_q, grid, blk, 0, st, op, T, p, q, c->partials);
+        c->probe_end(0);
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(pq)));
         hipLaunchKernelGGL(k_cg_xr, grid, blk, 0, st, g, T, S, gen, p, q, x, r, c->partials);

@@ -254,6 +254,14 @@ class Device:
         check(self.lib.cfd_time_kernel(self._h, int(kernel), int(reps), C.byref(out)))
         return out.value
 
+    def probe(self, kernel):
+        check(self.lib.cfd_probe(self._h, int(kernel)))
+
+    def probe_read(self):
+        n, us = C.c_int(), C.c_double()
+        check(self.lib.cfd_probe_read(self._h, C.byref(n), C.byref(us)))
+        return n.value, us.value
+
     def enable_phase_timing(self, on=True):
         check(self.lib.cfd_enable_phase_timing(self._h, int(on)))
 

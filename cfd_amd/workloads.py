@@ -1,0 +1,49 @@
+"""Synthetic benchmark workload of SURVEY.md 8(d): periodic-i channel with walls and
+pressure-gradient forcing on an N x N rectangular mesh (CONFIG in the reference's schema)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def channel_forced_config(n, turbulent=False, max_iter=2, tol=1.0e-8, ratio_j=1.0, steps=1):
+    mesh_params = dict(length_i=1.0, length_j=1.0, count_i=n, count_j=n, ratio_i=1.0, ratio_j=ratio_j)
+    boundary = {
+        "i_min": {"type": "periodic", "range": (0, n - 1)},
+        "i_max": {"type": "periodic", "range": (0, n - 1)},
+        "j_min": {"type": "wall", "range": (0, n - 1)},
+        "j_max": {"type": "wall", "range": (0, n - 1)},
+        "pressure_reference": {"cell": (0, 0), "value": 0.0},
+    }
+    initial = {"u": None, "v": 0.0, "p": 0.0}
+    turbulence = {"enabled": False, "model": "none"}
+    if turbulent:
+        turbulence = {"enabled": True, "model": "k_omega", "update_interval": 1}
+        initial["scalars"] = {"k": 1.0e-4, "omega": 10.0}
+    config = {
+        "case_name": "channel_forced",
+        "physics": {"nu": 1.0e-3, "pressure_gradient": (-0.1, 0.0)},
+        "time": {"cfl": 0.5, "cfl_diff": 0.5, "dt_max": 1.0e-3, "dt_min": 0.0, "max_steps": steps},
+        "solver": {
+            "scheme": "simple", "rhie_chow": True,
+            "momentum": {"tol": tol, "maxiter": 500},
+            "pressure": {"tol": tol, "maxiter": 500},
+            "turbulence_solver": {"tol": tol, "maxiter": 500},
+            "simple": {"max_iter": max_iter, "continuity_tol": 0.0, "relax_u": 0.7, "relax_v": 0.7, "relax_p": 0.3},
+        },
+        "restart": {"enabled": False},
+        "boundary": boundary,
+        "turbulence": turbulence,
+        "initial": initial,
+        "post": {"plot_interval": 0, "save_interval": 0, "print_interval": 0},
+    }
+    return config, mesh_params
+
+
+def perturbed_parabola_rows(n, y_nodes, seed=1234, u_max=1.0):
+    """u = U (1 - (2y/H - 1)^2) + 1e-3 N(0,1) on the (Ni, Nj) interior (rect mesh: cell-centre
+    y is the mid-point of the node rows)."""
+    y_nodes = np.asarray(y_nodes)
+    yc = 0.5 * (y_nodes[1:] + y_nodes[:-1])
+    h = float(y_nodes[-1] - y_nodes[0])
+    rng = np.random.default_rng(seed)
+    return (u_max * (1.0 - (2.0 * yc / h - 1.0) ** 2))[None, :] + 1.0e-3 * rng.standard_normal((n, n))

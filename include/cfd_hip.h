@@ -223,6 +223,11 @@ int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, in
  * stream.  kernel: 0 = pressure SpMV, 1 = Jacobi smoother sweep (finest level),
  * 2 = momentum RHS, 3 = batched momentum SpMV, 4 = residual+restrict, 5 = continuity        */
 int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us);
+/* live probe: record a HIP-event pair on the context stream around EVERY launch of one hot
+ * kernel (same ids as cfd_time_kernel; -1 = off) while the solver runs, up to 4096 launches;
+ * cfd_probe_read returns how many launches were timed and their average duration.        */
+int cfd_probe(cfd_ctx *ctx, int kernel);
+int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us);
 /* accumulated device time per phase since the last reset (HIP events), microseconds:
  * {bc, adv(rhs), mom, press, corr, cont, turb, dt}                                          */
 int cfd_phase_times(cfd_ctx *ctx, double out[8], int reset);
