@@ -9,11 +9,10 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
     torchrun ... bench.py --gpus N ...                        (one rank per GPU)
 
 The JSON line also carries
-  roofline     : the multigrid Jacobi smoother sweep on the finest level (the kernel with the
-                 largest share of device time), timed live with HIP-event pairs around every
-                 launch inside the timed steps; achieved = 48 B/cell * Ni*Nj / avg duration
-                 (x, b, c_i, c_j, D read + x' written: 5R + 1W planes; SURVEY.md 8(d) lists 64 B
-                 for five stored coefficients, this build stores three).
+  roofline     : the finest-level multigrid smoother kernel k_mg_up<true> (prolongation + two
+                 fused damped-Jacobi sweeps + the PCG dot product in one pass), timed live with
+                 HIP-event pairs around every launch inside the timed steps; achieved =
+                 50 B/cell * Ni*Nj / avg duration (x, e/4, b, c_i, c_j, D read + x' written).
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
                  factor-once LU pressure) timed on this host, bounded sample.
 """
@@ -32,7 +31,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SMOOTHER_BYTES_PER_CELL = 48   # x, b, c_i, c_j, D read + x' written (3 coefficient planes, not the 5 of SURVEY 8(d))
+SMOOTHER_BYTES_PER_CELL = 50   # k_mg_up: x, e/4, b, c_i, c_j, D read + x' written, for TWO sweeps + prolongation
 
 
 def setup_device(n, turbulent, max_iter, tol, device):
@@ -103,7 +102,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--probe", type=int, default=1, help="kernel id for the live roofline probe")
+    ap.add_argument("--probe", type=int, default=7, help="kernel id for the live roofline probe")
     args = ap.parse_args()
 
     import torch
@@ -155,10 +154,11 @@ def main():
 
     out = None
     if rank == 0:
-        kernel_names = {0: "pressure SpMV (k_cg_q)", 1: "MG Jacobi smoother sweep, finest level (k_mg_jacobi)",
+        kernel_names = {0: "pressure SpMV (k_cg_q)",
+                        1: "MG pre-smoother, finest level: 2 fused Jacobi sweeps + residual + restrict (k_mg_down<true>)",
                         2: "momentum RHS (k_momentum_rhs)", 3: "batched momentum operator (k_bi_apply<2>)",
-                        4: "residual+restrict (k_mg_restrict)"}
-        bytes_per_cell = {0: 40, 1: SMOOTHER_BYTES_PER_CELL, 2: 120, 3: 72, 4: 42}[args.probe]
+                        7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
+        bytes_per_cell = {0: 40, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL}[args.probe]
         achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,

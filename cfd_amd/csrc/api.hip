@@ -349,8 +349,8 @@ int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node) {
     hipLaunchKernelGGL((k_transpose<true>), grid, blk, 0, c->stream, g, n0, n1, 2, 0, 0, c->stage_a, c->kry[13]);
     hipLaunchKernelGGL((k_transpose<true>), grid, blk, 0, c->stream, g, n0, n1, 2, 1, 0, c->stage_a, c->kry[14]);
     CFD_HIP(hipGetLastError());
-    // plane index of node (a, b) is b * pitch + a + 1
-    CFD_TRY(launch_metrics_from_nodes(c, c->kry[13] + 1, c->kry[14] + 1, g.pitch));
+    // node (a, b) sits at plane index g.at(a, b)
+    CFD_TRY(launch_metrics_from_nodes(c, c->kry[13] + g.at(0, 0), c->kry[14] + g.at(0, 0), g.pitch));
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
     c->p_built = false;
@@ -420,9 +420,9 @@ int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, 
     return CFD_OK;
 }
 
-int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int min_size) {
+int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused) {
     CTX(ctx);
-    (void)min_size;   // the hierarchy shape is fixed at cfd_create (coarsen while a dimension > 4)
+    c->mg_fused = fused ? 1 : 0;
     if (nu_pre < 1 || nu_post < 0 || !(omega > 0.0 && omega <= 1.0) || coarse_sweeps < 1) {
         set_error("cfd_set_multigrid: bad parameters"); return CFD_E_ARG;
     }

@@ -1,7 +1,7 @@
 // Internal declarations shared by the HIP translation units of libcfd_hip.so.
 // gfx950 only.  Device layout: planes [jg][ig], ig contiguous; element (ig, jg) of a
-// ghosted (Ni+2) x (Nj+2) plane lives at jg * pitch + ig + 1 so that interior cell
-// i = 0 (ig = 1) is 16-byte aligned.  Face planes share the geometry: i-face f (west
+// ghosted (Ni+2) x (Nj+2) plane lives at (jg + 1) * pitch + ig + 1 (one spare row on each
+// side, see Geo) so that interior cell i = 0 (ig = 1) is 16-byte aligned.  Face planes share the geometry: i-face f (west
 // face of cell f) sits at the index of cell f, j-face g (south face) at cell g.
 #pragma once
 
@@ -25,9 +25,12 @@ constexpr int MAX_LEVELS = 24;
 
 struct Geo {
     int ni, nj, pitch;
-    __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)jg * pitch + ig + 1; }
-    __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + 1) * pitch + i + 2; }
-    __host__ inline size_t plane_elems() const { return (size_t)(nj + 2) * pitch; }
+    // two ghost rows below and above the interior (rows -2, -1 and nj, nj+1): the inner pair is the
+    // reference's ghost layer, the outer pair is the extra halo row of the two-sweep fused kernels
+    // and of the j-slab exchange.  ghosted index jg = j + 1.
+    __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)(jg + 1) * pitch + ig + 1; }
+    __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + 2) * pitch + i + 2; }
+    __host__ inline size_t plane_elems() const { return (size_t)(nj + 4) * pitch; }
 };
 
 inline int pitch_for(int ni) { return ((ni + 4) + 31) / 32 * 32; }
@@ -137,6 +140,7 @@ struct Ctx {
     int mom_maxiter = 200, p_maxiter = 200, turb_maxiter = 200, freeze_pressure = 1;
     int mg_pre = 2, mg_post = 2, mg_coarse_sweeps = 40, mg_min = 4;
     double mg_omega = 0.8;
+    int mg_fused = 1;            // fused marching V-cycle kernels where applicable
     double k_clip = 1e-10, omega_clip = 1e-10;
     double dt_ap = -1.0;          // dt the a_P plane was built with
 

@@ -19,6 +19,8 @@
 // products are wave-shuffle + LDS reductions into per-workgroup partials followed by a
 // fixed-order single-workgroup pass (deterministic, no atomics).  Krylov scalars stay on
 // the device; the host reads one residual norm per iteration.
+#include <cstdlib>
+
 #include "internal.h"
 
 namespace cfd {
@@ -538,6 +540,227 @@ __global__ void k_mg_coarsest(OpDev op, const double *b, double omega, int sweep
     }
 }
 
+
+// ------------------------------------------------------------------ fused marching multigrid kernels
+// One wavefront owns a column strip: lane = column, it marches down the rows of a segment.
+// Vertical neighbours stay in registers (sliding windows), horizontal neighbours come from
+// lane shuffles, every plane row is loaded exactly once per wave as one coalesced 512-byte
+// run.  Two Jacobi sweeps are fused per pass (temporal blocking): strips overlap by HALO = 2
+// columns on each side (60 of 64 lanes produce output) and segments by 2 rows.
+//   k_mg_down: x = two damped-Jacobi sweeps from a zero guess, then the residual b - A x is
+//              summed over 2x2 aggregates straight into the coarse right-hand side.
+//   k_mg_up  : x' = two sweeps on (x + P e); at the finest level also (b, x') for PCG.
+// Cells outside the domain are neutral (x = b = 0, D = 1, couplings 0); periodic axes wrap.
+constexpr int MH = 2;             // horizontal halo = number of fused sweeps
+constexpr int MW = 64 - 2 * MH;   // output columns per wave
+
+struct RowC {
+    double b, d, inv, cw, ce, cs, cn;
+};
+
+__device__ __forceinline__ int wrap_index(int v, int n, int per) {
+    if (v >= 0 && v < n) return v;
+    if (!per) return -1;
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+// rows leave the domain by at most a few cells: one conditional add / subtract is enough
+__device__ __forceinline__ int wrap_row(int j, int n, int per) {
+    if (j >= 0 && j < n) return j;
+    if (!per) return -1;
+    return j < 0 ? j + n : j - n;
+}
+
+// 1/d without the IEEE division sequence: v_rcp_f64 + two Newton steps (the V-cycle is a
+// preconditioner; the last bit of the smoother does not matter, its instruction count does)
+__device__ __forceinline__ double fast_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+// lane i <- lane i-1 / lane i+1 through DPP wave shifts (VALU, no LDS round trip)
+__device__ __forceinline__ double lane_left(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_right(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Unconditional loads from a clamped (always valid) cell: lanes / rows outside the domain
+// read finite garbage that only ever multiplies x = 0.
+__device__ __forceinline__ RowC load_rowc(const OpDev &op, const double *b, size_t c) {
+    RowC r;
+    r.b = b[c]; r.d = op.D[c]; r.cw = op.ci[c]; r.ce = op.ci[c + 1]; r.cs = op.cj[c]; r.cn = op.cj[c + op.g.pitch];
+    r.inv = fast_rcp(r.d);
+    return r;
+}
+
+__device__ __forceinline__ double jac(double xc, double xs, double xn, const RowC &r, double omega) {
+    const double xl = lane_left(xc), xr = lane_right(xc);
+    const double ax = r.d * xc - (r.cw * xl + r.ce * xr + r.cs * xs + r.cn * xn);
+    return xc + omega * (r.b - ax) * r.inv;
+}
+__device__ __forceinline__ double resid(double xc, double xs, double xn, const RowC &r) {
+    const double xl = lane_left(xc), xr = lane_right(xc);
+    return r.b - (r.d * xc - (r.cw * xl + r.ce * xr + r.cs * xs + r.cn * xn));
+}
+
+struct MarchGeo {
+    int nstrips, nsegs, Ls;
+};
+static inline MarchGeo march_geo(const Geo &g) {
+    MarchGeo m;
+    m.nstrips = (g.ni + MW - 1) / MW;
+    int Ls = 16;
+    while (Ls > 4 && (long)m.nstrips * ((g.nj + Ls - 1) / Ls) < 8192) Ls /= 2;
+    m.Ls = Ls;
+    m.nsegs = (g.nj + Ls - 1) / Ls;
+    return m;
+}
+
+template <bool FINE>
+__global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const double *b, double omega, double *x, Geo gc,
+                                                 double *bc) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+        const int iraw = strip * MW - MH + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        auto rowc = [&](int j, bool &valid) -> RowC {
+            const int jm = wrap_row(j, g.nj, op.per_j);
+            valid = cvalid && jm >= 0;
+            return load_rowc(op, b, (size_t)(max(jm, 0) + 2) * P + colo);
+        };
+        bool v2, v1;
+        RowC rc2 = rowc(j0 - 2, v2);
+        RowC rc1 = rowc(j0 - 1, v1);
+        double x1a = v2 ? omega * rc2.b * rc2.inv : 0.0, x1b = v1 ? omega * rc1.b * rc1.inv : 0.0, x1c;
+        double x2a = 0.0, x2b = 0.0, x2c = 0.0, rsum = 0.0;
+        for (int jr = j0; jr < j1 + 2; jr += 2) {
+            RowC rn[2];
+            bool vn[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) rn[q] = rowc(jr + q, vn[q]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = jr + q;                 // newest row
+                const RowC rc0 = rn[q];
+                x1c = vn[q] ? omega * rc0.b * rc0.inv : 0.0;
+                // second sweep on row j-1
+                x2c = jac(x1b, x1a, x1c, rc1, omega);
+                if (!v1) x2c = 0.0;                   // outside the domain: x = 0
+                if (j - 1 >= j0 && j - 1 < j1 && out) x[(size_t)(j + 1) * P + colo] = x2c;
+                // residual on row j-2
+                const int jo = j - 2;
+                const double res = resid(x2b, x2a, x2c, rc2);
+                if (jo >= j0 && jo < j1) {
+                    rsum += res;
+                    if (((jo - j0) & 1) || jo == j1 - 1) {
+                        const double tot = rsum + lane_right(rsum);
+                        if (out && !((lane - MH) & 1)) bc[gc.cell(iraw >> 1, jo >> 1)] = (iraw + 1 < g.ni) ? tot : rsum;
+                        rsum = 0.0;
+                    }
+                }
+                x1a = x1b; x1b = x1c;
+                x2a = x2b; x2b = x2c;
+                rc2 = rc1; rc1 = rc0;
+                v2 = v1; v1 = vn[q];
+            }
+        }
+    }
+}
+
+template <bool FINE>
+__global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const double *b, const double *x, Geo gc,
+                                               const double *e, double omega, double *xn, double *partials) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    double dot = 0.0;
+    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+        const int iraw = strip * MW - MH + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + 2;
+        const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        auto rowc = [&](int j, bool &valid, double &x0) -> RowC {
+            const int jm = wrap_row(j, g.nj, op.per_j);
+            valid = cvalid && jm >= 0;
+            const int js = max(jm, 0);
+            const size_t c = (size_t)(js + 2) * P + colo;
+            const double xv = x[c] + e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
+            x0 = valid ? xv : 0.0;
+            return load_rowc(op, b, c);
+        };
+        bool v2, v1;
+        double x0a, x0b, x0c;
+        RowC rc2 = rowc(j0 - 2, v2, x0a);
+        RowC rc1 = rowc(j0 - 1, v1, x0b);
+        double x1a = 0.0, x1b = 0.0, x1c = 0.0;
+        for (int jr = j0; jr < j1 + 2; jr += 2) {
+            RowC rn[2];
+            double xl[2];
+            bool vn[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) rn[q] = rowc(jr + q, vn[q], xl[q]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = jr + q;
+                const RowC rc0 = rn[q];
+                x0c = xl[q];
+                // first sweep on row j-1
+                x1c = jac(x0b, x0a, x0c, rc1, omega);
+                if (!v1) x1c = 0.0;
+                // second sweep on row j-2
+                const int jo = j - 2;
+                const double x2 = jac(x1b, x1a, x1c, rc2, omega);
+                if (jo >= j0 && jo < j1 && out) {
+                    xn[(size_t)(jo + 2) * P + colo] = x2;
+                    if (FINE) dot += rc2.b * x2;
+                }
+                x0a = x0b; x0b = x0c;
+                x1a = x1b; x1b = x1c;
+                rc2 = rc1; rc1 = rc0;
+                v2 = v1; v1 = vn[q];
+            }
+        }
+    }
+    if (FINE) {
+        __shared__ double sm[4];
+        const double w = wsum(dot);
+        if (lane == 0) sm[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+static inline bool level_fusable(const Ctx *c, const Level &F, const Level &C) {
+    return c->mg_fused && c->mg_pre == 2 && c->mg_post == 2 && F.g.ni >= 16 && F.g.nj >= 16 &&
+           C.g.ni == (F.g.ni + 1) / 2 && C.g.nj == (F.g.nj + 1) / 2;
+}
+static inline int march_blocks(const MarchGeo &m) {
+    const long items = (long)m.nstrips * m.nsegs;
+    const long nb = (items + 3) / 4;
+    return (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
+}
+
 static inline OpDev level_op(const Ctx *c, const Level &L) {
     return OpDev{L.ci, L.cj, L.D, L.g, c->pp_per_i, c->pp_per_j};
 }
@@ -601,7 +824,7 @@ int build_pressure_hierarchy(Ctx *c) {
 
 // One V-cycle: z ~= A^-1 r starting from zero.  The result lands in *zout, which is
 // either z0 or z1 (Jacobi ping-pong).
-static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout) {
+static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks) {
     hipStream_t st = c->stream;
     const int nl = (int)c->levels.size();
     const double om = c->mg_omega;
@@ -615,22 +838,31 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     }
     for (int l = 0; l < nl - 1; ++l) {
         const Level &L = c->levels[l];
+        const Level &C = c->levels[l + 1];
         const OpDev op = level_op(c, L);
+        if (level_fusable(c, L, C)) {
+            const MarchGeo mgeo = march_geo(L.g);
+            const dim3 grid(march_blocks(mgeo));
+            if (l == 0) {
+                c->probe_begin(1);
+                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], C.g, C.b);
+                c->probe_end(1);
+            } else {
+                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], C.g, C.b);
+            }
+            CFD_HIP(hipGetLastError());
+            continue;
+        }
         const Tiling T = tiling(L.g);
         hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
         for (int s = 1; s < pre; ++s) {
-            if (l == 0) c->probe_begin(1);
             hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
-            if (l == 0) c->probe_end(1);
             std::swap(cur[l], oth[l]);
         }
-        const Level &C = c->levels[l + 1];
         int fi, fj;
         factors(L, C, fi, fj);
         const Tiling Tc = tiling(C.g);
-        if (l == 0) c->probe_begin(4);
         hipLaunchKernelGGL(k_mg_restrict, dim3(Tc.blocks), block2d(), 0, st, op, rhs[l], cur[l], C.g, Tc, fi, fj, C.b);
-        if (l == 0) c->probe_end(4);
         CFD_HIP(hipGetLastError());
     }
     {
@@ -650,18 +882,34 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         }
         CFD_HIP(hipGetLastError());
     }
+    *dot_blocks = 0;
     for (int l = nl - 2; l >= 0; --l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
         const OpDev op = level_op(c, L);
+        if (level_fusable(c, L, C)) {
+            const MarchGeo mgeo = march_geo(L.g);
+            const dim3 grid(march_blocks(mgeo));
+            if (l == 0) {
+                c->probe_begin(7);
+                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], C.g, cur[l + 1], om,
+                                   oth[l], c->partials);
+                c->probe_end(7);
+                *dot_blocks = (int)grid.x;
+            } else {
+                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], C.g, cur[l + 1], om,
+                                   oth[l], c->partials);
+            }
+            std::swap(cur[l], oth[l]);
+            CFD_HIP(hipGetLastError());
+            continue;
+        }
         const Tiling T = tiling(L.g);
         int fi, fj;
         factors(L, C, fi, fj);
         hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, C.g, fi, fj, cur[l + 1], cur[l]);
         for (int s = 0; s < post; ++s) {
-            if (l == 0) c->probe_begin(1);
             hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
-            if (l == 0) c->probe_end(1);
             std::swap(cur[l], oth[l]);
         }
         CFD_HIP(hipGetLastError());
@@ -678,7 +926,8 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
 int vcycle(Ctx *c, const double *r, double *z) {
     double *out = nullptr;
     double *z1 = c->kry[15];
-    CFD_TRY(vcycle_impl(c, r, z, z1, &out));
+    int db = 0;
+    CFD_TRY(vcycle_impl(c, r, z, z1, &out, &db));
     if (out != z) CFD_HIP(hipMemcpyAsync(z, out, c->g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return CFD_OK;
 }
@@ -761,11 +1010,16 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     while (it < maxiter) {
         const int gen = it & 1;
         double *z = nullptr;
-        CFD_TRY(vcycle_impl(c, r, za, zb, &z));
-        CVecs<1> a1{{r}}, a2{{z}};
-        hipLaunchKernelGGL((k_dot<1>), grid, blk, 0, st, g, T, a1, a2, c->partials);
-        CFD_HIP(hipGetLastError());
-        CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rz[gen])));
+        int db = 0;
+        CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db));
+        if (db > 0) {
+            CFD_TRY(finish_to(c, db, 1, CG_OFF_OF(rz[gen])));     // (r, z) came out of the fused up-sweep
+        } else {
+            CVecs<1> a1{{r}}, a2{{z}};
+            hipLaunchKernelGGL((k_dot<1>), grid, blk, 0, st, g, T, a1, a2, c->partials);
+            CFD_HIP(hipGetLastError());
+            CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rz[gen])));
+        }
         hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);
         c->probe_begin(0);
         hipLaunchKernelGGL(k_cg_q, grid, blk, 0, st, op, T, p, q, c->partials);
@@ -815,14 +1069,15 @@ static int bicgstab_mg(Ctx *c, const double *b, double *x, double tol, int maxit
         const int gen = it & 1;
         hipLaunchKernelGGL((k_bi_p<1>), grid, blk, 0, st, g, T, S, gen, it == 0, act, cv(r), cv(v), p);
         double *out = nullptr;
-        CFD_TRY(vcycle_impl(c, p.p[0], w0, w1, &out));
+        int db = 0;
+        CFD_TRY(vcycle_impl(c, p.p[0], w0, w1, &out, &db));
         CFD_HIP(hipMemcpyAsync(ph, out, g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL((k_bi_apply<1, false, 0>), grid, blk, 0, st, op, T, (const double *)nullptr, act, cv(p),
                            CVecs<1>{{ph}}, cv(rh), v, c->partials);
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, 1, OFF_OF(sigma[0])));
         hipLaunchKernelGGL((k_bi_s<1>), grid, blk, 0, st, g, T, S, gen, act, cv(v), r);
-        CFD_TRY(vcycle_impl(c, r.p[0], w0, w1, &out));
+        CFD_TRY(vcycle_impl(c, r.p[0], w0, w1, &out, &db));
         CFD_HIP(hipMemcpyAsync(sh, out, g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL((k_bi_apply<1, false, 1>), grid, blk, 0, st, op, T, (const double *)nullptr, act, cv(r),
                            CVecs<1>{{sh}}, cv(r), t, c->partials);
@@ -856,6 +1111,7 @@ int pressure_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, 
     return bicgstab_mg(c, b, x, tol, maxiter, iters, relres);
 }
 
+
 // ------------------------------------------------------------------ kernel timing (bench.py)
 int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
     if (reps < 1) reps = 1;
@@ -878,7 +1134,13 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                 case 1: {
                     if (!c->p_built) { set_error("pressure operator not built"); return CFD_E_STATE; }
                     const OpDev op = level_op(c, c->levels[0]);
-                    hipLaunchKernelGGL(k_mg_jacobi, grid, blk, 0, st, op, T, c->kry[1], c->kry[4], c->mg_omega, c->kry[5]);
+                    if (c->levels.size() > 1 && level_fusable(c, c->levels[0], c->levels[1])) {
+                        const MarchGeo mgeo = march_geo(g);
+                        hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->kry[1],
+                                           c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_omega, c->kry[5], c->partials);
+                    } else {
+                        hipLaunchKernelGGL(k_mg_jacobi, grid, blk, 0, st, op, T, c->kry[1], c->kry[4], c->mg_omega, c->kry[5]);
+                    }
                     break;
                 }
                 case 2:

@@ -112,8 +112,9 @@ class Device:
         check(self.lib.cfd_set_solver(self._h, float(mom_tol), int(mom_maxiter), float(p_tol), int(p_maxiter),
                                       float(turb_tol), int(turb_maxiter), int(bool(freeze_pressure))))
 
-    def set_multigrid(self, nu_pre=2, nu_post=2, omega=0.8, coarse_sweeps=40):
-        check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(omega), int(coarse_sweeps), 4))
+    def set_multigrid(self, nu_pre=2, nu_post=2, omega=0.8, coarse_sweeps=40, fused=True):
+        check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(omega), int(coarse_sweeps),
+                                         int(bool(fused))))
 
     def set_turbulence_clip(self, k_min, omega_min):
         check(self.lib.cfd_set_turbulence_clip(self._h, float(k_min), float(omega_min)))

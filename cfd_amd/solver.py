@@ -262,7 +262,8 @@ def configure_device(dev, config, geometry, nu, turb_on):
                    pressure_cfg.get("tol", 1.0e-8), pressure_cfg.get("maxiter", 200),
                    turb_solver_cfg.get("tol", 1.0e-8), turb_solver_cfg.get("maxiter", 200),
                    pressure_cfg.get("freeze_operator", True))
-    dev.set_multigrid(mg.get("nu_pre", 2), mg.get("nu_post", 2), mg.get("omega", 0.8), mg.get("coarse_sweeps", 40))
+    dev.set_multigrid(mg.get("nu_pre", 2), mg.get("nu_post", 2), mg.get("omega", 0.8), mg.get("coarse_sweeps", 40),
+                      mg.get("fused", True))
     params = config.get("turbulence", {}).get("params", {})
     dev.set_turbulence_clip(params.get("k_min", 1.0e-10), params.get("omega_min", 1.0e-10))
     tables = BoundaryTables(config["boundary"], dev.ni, dev.nj, geometry, nu, turb_on)

@@ -128,8 +128,9 @@ int cfd_set_physics(cfd_ctx *ctx, double nu, double dpdx, double dpdy, int rhie_
  * operator of the run (cached pyamg hierarchy, solver.py:821-833).       */
 int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, int p_maxiter,
                    double turb_tol, int turb_maxiter, int freeze_pressure);
-/* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps            */
-int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int min_size);
+/* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps; fused = 1 uses
+ * the temporally blocked (two sweeps per pass) marching kernels when nu_pre = nu_post = 2  */
+int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused);
 /* turbulence clip after the k/omega solve (solver.py:1147-1151)                       */
 int cfd_set_turbulence_clip(cfd_ctx *ctx, double k_min, double omega_min);
 

@@ -305,6 +305,51 @@ def test_linear_algebra_against_scipy():
     dev.close()
 
 
+def _bc_variant(kind, ni, nj):
+    wall_i = {"type": "wall", "range": (0, nj - 1)}
+    wall_j = {"type": "wall", "range": (0, ni - 1)}
+    if kind == "per_i":
+        return {"i_min": {"type": "periodic", "range": (0, nj - 1)}, "i_max": {"type": "periodic", "range": (0, nj - 1)},
+                "j_min": wall_j, "j_max": wall_j, "pressure_reference": {"cell": (3, 2), "value": 0.0}}
+    if kind == "per_j":
+        return {"i_min": wall_i, "i_max": wall_i,
+                "j_min": {"type": "periodic", "range": (0, ni - 1)}, "j_max": {"type": "periodic", "range": (0, ni - 1)},
+                "pressure_reference": {"cell": (0, 0), "value": 0.0}}
+    return {"i_min": {"type": "inlet", "range": (0, nj - 1), "velocity": (1.0, 0.0)},
+            "i_max": {"type": "outlet", "range": (0, nj - 1), "pressure": 0.0},
+            "j_min": wall_j, "j_max": wall_j, "pressure_reference": {"cell": (0, 0), "value": 0.0}}
+
+
+@pytest.mark.parametrize("kind,ni,nj", [("per_i", 64, 48), ("per_i", 130, 67), ("per_j", 33, 40), ("inout", 50, 37),
+                                         ("inout", 257, 129)])
+def test_fused_vcycle_matches_unfused(kind, ni, nj):
+    """The temporally blocked marching kernels (two Jacobi sweeps per pass, residual+restrict and
+    prolongation folded in) compute the same V-cycle as the one-kernel-per-sweep path."""
+    mesh = orc.rect_mesh(2.0, 1.0, ni, nj, 1.0, 1.0 + 1.6 / nj)      # max/min dy ~ 5 (point smoother regime)
+    dev = _device_for(mesh, _bc_variant(kind, ni, nj), 1e-3, turbulent=False)
+    rng = np.random.default_rng(ni * 1000 + nj)
+    f = {k: np.zeros((ni + 2, nj + 2)) for k in ("u", "v", "p", "nu_t")}
+    dev.upload_fields(f)
+    dev.momentum_diagonal(3e-3, 1.0)
+    ci, cj, diag, _ = dev.pressure_system()
+    per_i, per_j = kind == "per_i", kind == "per_j"
+    a = orc.five_point_matrix(diag, ci[:-1], ci[1:], cj[:, :-1], cj[:, 1:], per_i, per_j)
+    r = rng.standard_normal((ni, nj))
+    dev.set_multigrid(2, 2, 0.8, 40, fused=False)
+    z_ref = dev.vcycle(r)
+    dev.set_multigrid(2, 2, 0.8, 40, fused=True)
+    z = dev.vcycle(r)
+    assert rel_l2(z, z_ref) < 1e-12
+    x_true = rng.standard_normal((ni, nj))
+    b = a.dot(x_true.ravel()).reshape(ni, nj)
+    for fused in (False, True):
+        dev.set_multigrid(2, 2, 0.8, 40, fused=fused)
+        sol, iters, relres = dev.pressure_krylov(b, tol=1e-12, maxiter=300)
+        assert relres <= 1e-12 and iters < 80, (fused, iters, relres)
+        assert np.linalg.norm((a.dot(sol.ravel()) - b.ravel())) <= 1e-10 * np.linalg.norm(b.ravel())
+    dev.close()
+
+
 @pytest.mark.parametrize("n", [512])
 def test_properties_at_scale(n):
     """Size-independent checks where the oracle is too slow: (1) the pressure correction makes
