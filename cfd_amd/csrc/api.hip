@@ -553,7 +553,9 @@ static int do_predictor(Ctx *c, double dt, double res[3]) {
         double *b[2] = {c->bu, c->bv}, *x[2] = {c->U1(), c->V1()};
         double rms[2];
         int it = 0;
-        CFD_TRY(momentum_like_solve(c, op, b, x, 2, c->mom_tol, c->mom_maxiter, &it, c->stats.mom_relres, rms));
+        const double *x0[2] = {c->U(), c->V()};
+        CFD_TRY(momentum_like_solve(c, op, b, x, c->warm_start ? x0 : nullptr, 2, c->mom_tol, c->mom_maxiter, &it,
+                                    c->stats.mom_relres, rms));
         c->stats.mom_iters = it;
         res[1] = rms[0];
         res[2] = rms[1];
@@ -658,7 +660,9 @@ int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
     const OpDev op{c->ti, c->tj, c->tp, c->g, c->per_i, c->per_j};
     double *b[2] = {c->bu, c->bv}, *x[2] = {c->k, c->omega};
     int it = 0;
-    CFD_TRY(momentum_like_solve(c, op, b, x, 2, c->turb_tol, c->turb_maxiter, &it, c->stats.k_relres, nullptr));
+    const double *x0[2] = {c->k, c->omega};
+    CFD_TRY(momentum_like_solve(c, op, b, x, c->warm_start ? x0 : nullptr, 2, c->turb_tol, c->turb_maxiter, &it,
+                                c->stats.k_relres, nullptr));
     c->stats.k_iters = it;
     CFD_TRY(launch_clip(c, c->k, c->k_clip));
     CFD_TRY(launch_clip(c, c->omega, c->omega_clip));
@@ -736,7 +740,9 @@ int cfd_momentum_solve(cfd_ctx *ctx, double res[2]) {
     const OpDev op{c->ai, c->aj, c->ap, c->g, c->per_i, c->per_j};
     double *b[2] = {c->bu, c->bv}, *x[2] = {c->U1(), c->V1()};
     int it = 0;
-    CFD_TRY(momentum_like_solve(c, op, b, x, 2, c->mom_tol, c->mom_maxiter, &it, c->stats.mom_relres, res));
+    const double *x0[2] = {c->U(), c->V()};
+    CFD_TRY(momentum_like_solve(c, op, b, x, c->warm_start ? x0 : nullptr, 2, c->mom_tol, c->mom_maxiter, &it,
+                                c->stats.mom_relres, res));
     c->stats.mom_iters = it;
     // the fine-grained API works in place on the current planes (like the reference): copy the interior
     for (int q = 0; q < 2; ++q) {

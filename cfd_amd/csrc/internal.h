@@ -140,6 +140,7 @@ struct Ctx {
     int mom_maxiter = 200, p_maxiter = 200, turb_maxiter = 200, freeze_pressure = 1;
     int mg_pre = 2, mg_post = 2, mg_coarse_sweeps = 40, mg_min = 4;
     double mg_omega = 0.8;
+    int warm_start = 1;          // Krylov initial guess = previous field (reference: zero)
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
     double k_clip = 1e-10, omega_clip = 1e-10;
     double dt_ap = -1.0;          // dt the a_P plane was built with
@@ -204,7 +205,7 @@ int launch_metrics_from_rect(Ctx *c, const double *x1, const double *y1);
 // linalg.hip
 int reduce_finish(Ctx *c, int nq, int scal_off);       // partials -> scal[scal_off .. +nq)
 int read_scalars(Ctx *c, int off, int n, double *host);
-int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], int nb,
+int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2], int nb,
                         double tol, int maxiter, int *iters, double relres[2], double rms[2]);
 int build_pressure_hierarchy(Ctx *c);
 int pressure_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres);

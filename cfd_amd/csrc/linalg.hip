@@ -313,6 +313,31 @@ __global__ void k_bi_init(Geo g, Tiling T, CVecs<NB> b, Vecs<NB> r, Vecs<NB> rha
     block_sums<NB>(acc, partials);
 }
 
+// warm start: x = x0, r = rhat = b - A x0 ; partial[q] = (b, b), partial[NB+q] = (r, r)
+template <int NB>
+__global__ void k_bi_init_ws(OpDev op, Tiling T, CVecs<NB> b, CVecs<NB> x0, Vecs<NB> r, Vecs<NB> rhat, Vecs<NB> x,
+                             double *partials) {
+    const Geo g = op.g;
+    double acc[2 * NB];
+#pragma unroll
+    for (int q = 0; q < 2 * NB; ++q) acc[q] = 0.0;
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const double *xs = x0.p[q];
+            const double bv = b.p[q][c], xc = xs[c];
+            const double rv = bv - (op.D[c] * xc - offdiag(op, [xs](size_t n) { return xs[n]; }, c, i, j));
+            r.p[q][c] = rv;
+            rhat.p[q][c] = rv;
+            if (x.p[q] != xs) x.p[q][c] = xc;
+            acc[q] += bv * bv;
+            acc[NB + q] += rv * rv;
+        }
+    }
+    block_sums<2 * NB>(acc, partials);
+}
+
 static int finish_to(Ctx *c, int blocks, int nq, size_t scal_off_doubles) {
     c->n_red_blocks = blocks;
     return reduce_finish(c, nq, (int)scal_off_doubles);
@@ -322,8 +347,8 @@ static int finish_to(Ctx *c, int blocks, int nq, size_t scal_off_doubles) {
 
 // Jacobi-preconditioned BiCGStab for NB right-hand sides sharing one operator.
 template <int NB>
-static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], double tol, int maxiter,
-                           int *iters, double relres[2], double rms[2]) {
+static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
+                           double tol, int maxiter, int *iters, double relres[2], double rms[2]) {
     const Geo g = op.g;
     const Tiling T = tiling(g);
     const dim3 grid(T.blocks), blk = block2d();
@@ -348,18 +373,33 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
     };
     hipLaunchKernelGGL(k_inv_diag, grid, blk, 0, st, g, T, op.D, inv);
     CFD_HIP(hipMemsetAsync(S, 0, sizeof(BiScal), st));
-    hipLaunchKernelGGL((k_bi_init<NB>), grid, blk, 0, st, g, T, bc, r, rh, xv, c->partials);
-    CFD_HIP(hipGetLastError());
-    CFD_TRY(finish_to(c, T.blocks, NB, OFF_OF(rho[0][0])));
     double bb[2] = {0, 0}, rr[2] = {0, 0};
-    CFD_TRY(read_scalars(c, OFF_OF(rho[0][0]), NB, bb));
+    if (x0) {
+        // the reference starts from zero (scipy default); starting from the previous field only
+        // changes the iteration path, the stopping test |r| <= tol |b| is the reference's
+        CVecs<NB> x0c;
+        for (int q = 0; q < NB; ++q) x0c.p[q] = x0[q];
+        hipLaunchKernelGGL((k_bi_init_ws<NB>), grid, blk, 0, st, op, T, bc, x0c, r, rh, xv, c->partials);
+        CFD_HIP(hipGetLastError());
+        CFD_TRY(finish_to(c, T.blocks, 2 * NB, 0));
+        double both[4];
+        CFD_TRY(read_scalars(c, 0, 2 * NB, both));
+        for (int q = 0; q < NB; ++q) { bb[q] = both[q]; rr[q] = both[NB + q]; }
+        // rho[0][q] = (rhat, r) = (r, r)
+        CFD_HIP(hipMemcpyAsync(c->scal + OFF_OF(rho[0][0]), c->scal + NB, NB * sizeof(double), hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL((k_bi_init<NB>), grid, blk, 0, st, g, T, bc, r, rh, xv, c->partials);
+        CFD_HIP(hipGetLastError());
+        CFD_TRY(finish_to(c, T.blocks, NB, OFF_OF(rho[0][0])));
+        CFD_TRY(read_scalars(c, OFF_OF(rho[0][0]), NB, bb));
+        for (int q = 0; q < NB; ++q) rr[q] = bb[q];
+    }
     Act act{{0, 0}};
     int n_active = 0;
     for (int q = 0; q < NB; ++q) {
-        if (!(bb[q] == bb[q])) { set_error("momentum-like solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
-        act.a[q] = bb[q] > 0.0;
+        if (!(bb[q] == bb[q]) || !(rr[q] == rr[q])) { set_error("momentum-like solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
+        act.a[q] = rr[q] > 0.0 && sqrt(rr[q]) > tol * sqrt(bb[q]);
         n_active += act.a[q];
-        rr[q] = bb[q];
         relres[q] = 0.0;
     }
     int it = 0;
@@ -422,10 +462,10 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
     return CFD_OK;
 }
 
-int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], int nb, double tol,
-                        int maxiter, int *iters, double relres[2], double rms[2]) {
-    if (nb == 2) return bicgstab_jacobi<2>(c, op, b, x, tol, maxiter, iters, relres, rms);
-    return bicgstab_jacobi<1>(c, op, b, x, tol, maxiter, iters, relres, rms);
+int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
+                        int nb, double tol, int maxiter, int *iters, double relres[2], double rms[2]) {
+    if (nb == 2) return bicgstab_jacobi<2>(c, op, b, x, x0, tol, maxiter, iters, relres, rms);
+    return bicgstab_jacobi<1>(c, op, b, x, x0, tol, maxiter, iters, relres, rms);
 }
 
 // ------------------------------------------------------------------ multigrid kernels
