@@ -34,32 +34,40 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 50   # k_mg_up: x, e/4, b, c_i, c_j, D read + x' written, for TWO sweeps + prolongation
 
 
-def setup_device(n, turbulent, max_iter, tol, device):
+def setup_device(n, turbulent, max_iter, tol, device, world=1):
+    """One n x n slab per GPU of an n x (n * world) channel of height `world` (same cells, same cell
+    size on every rank: weak scaling); world = 1 is the single-GPU workload of SURVEY.md 8(d)."""
     from cfd_amd import _lib as L
     from cfd_amd.bc import BoundaryGeometry
-    from cfd_amd.device import Device
     from cfd_amd.mesh import rect_node_axes
+    from cfd_amd.slab import slab_device
     from cfd_amd.solver import StepControl, configure_device
     from cfd_amd.workloads import channel_forced_config, perturbed_parabola_rows
 
-    cfg, mp = channel_forced_config(n, turbulent, max_iter, tol)
+    cfg, mp = channel_forced_config(n, turbulent, max_iter, tol, nj=n * world, length_j=float(world))
     x, y = rect_node_axes(**mp)
-    dev = Device(n, n, device)
+    dev = slab_device(n, n * world, device)
     dev.mesh_from_rect(x, y)
     ctl = StepControl(cfg)
     configure_device(dev, cfg, BoundaryGeometry.from_rect_axes(x, y), cfg["physics"]["nu"], ctl.turb_on)
-    shape = (n + 2, n + 2)
+    shape = (n + 2, dev.nj + 2)
     f = np.zeros(shape)
-    f[1:-1, 1:-1] = perturbed_parabola_rows(n, y, seed=1234)
+    f[1:-1, 1:-1] = perturbed_parabola_rows(n, y, seed=1234, j_offset=dev.j_offset, nj_local=dev.nj)
     dev.upload(L.F_U, f)
+    dev.exchange(L.F_U)            # ghost rows at the cuts = the neighbours' rows
     f[:] = 0.0
     dev.upload(L.F_V, f)
     dev.upload(L.F_P, f)
     dev.upload(L.F_NUT, f)
     if turbulent:
-        f[1:-1, 1:-1] = 1.0e-4
+        f[:, :] = 1.0e-4           # uniform, ghost rows included (cut ghosts = neighbour values)
+        f[[0, -1], :] = 0.0
+        if dev.rank == 0:
+            f[:, 0] = 0.0
+        if dev.rank == dev.nranks - 1:
+            f[:, -1] = 0.0
         dev.upload(L.F_K, f)
-        f[1:-1, 1:-1] = 10.0
+        f[f != 0.0] = 10.0
         dev.upload(L.F_OMEGA, f)
     del f
     return dev, ctl, cfg
@@ -103,6 +111,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--probe", type=int, default=7, help="kernel id for the live roofline probe")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--shared-gpu", action="store_true",
+                    help="rehearsal only: all ranks use GPU 0 (with --backend gloo), numbers are not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -113,9 +124,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if args.shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if world > 1:
@@ -125,7 +141,7 @@ def main():
     from cfd_amd.solver import advance_one_step
 
     n = args.size
-    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local)
+    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, world)
     step = 0
     iters = []
     for _ in range(args.warmup):
@@ -144,7 +160,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_probe, probe_us = dev.probe_read()
@@ -169,12 +185,14 @@ def main():
             "metric": "cell-updates/s per outer step", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not args.shared_gpu else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
             "config": {"workload": f"synthetic {n}x{n} periodic channel with pressure-gradient forcing "
                                    f"({'k-omega' if args.turbulent else 'laminar'}), SIMPLE max_iter={args.max_iter}, "
                                    f"continuity_tol=0, cfl=cfl_diff=0.5, dt_max=1e-3, rtol={args.tol:g}",
                        "cells_per_gpu": n * n,
-                       "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (j-slab exchange not yet in)",
+                       "parallelism": "1 GPU" if world == 1 else
+                       f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel (height {world}), halo exchange + "
+                       f"all-reduce over RCCL, coarse multigrid levels replicated",
                        "inner_iterations": args.max_iter,
                        "mean_momentum_iters": float(it[:, 0].mean()), "mean_pressure_iters": float(it[:, 1].mean()),
                        "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,

@@ -97,6 +97,18 @@ SIGNATURES = {
     "cfd_enable_phase_timing": (C.c_int, [_vp, C.c_int]),
 }
 
+# j-slab communication callbacks (cfd_halo_fn, cfd_allreduce_fn, cfd_allgather_fn)
+HALO_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_int, C.c_int)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t)
+SIGNATURES.update({
+    "cfd_workspace_bytes_slab": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "cfd_create_slab": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int]),
+    "cfd_set_comm": (C.c_int, [_vp, HALO_FN, ALLREDUCE_FN, ALLGATHER_FN, _vp]),
+    "cfd_exchange_field": (C.c_int, [_vp, C.c_int]),
+    "cfd_level_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+})
+
 _lib = None
 
 
@@ -117,9 +129,16 @@ def load():
     return lib
 
 
+LAST_CALLBACK_ERROR = None      # exception raised inside a communication callback (cfd_amd.slab)
+
+
 def check(rc):
+    global LAST_CALLBACK_ERROR
     if rc != 0:
         msg = load().cfd_last_error().decode("utf-8", "replace")
+        cause, LAST_CALLBACK_ERROR = LAST_CALLBACK_ERROR, None
+        if cause is not None:
+            raise HipError(f"libcfd_hip error {rc}: {msg}: {cause!r}") from cause
         raise HipError(f"libcfd_hip error {rc}: {msg}")
 
 

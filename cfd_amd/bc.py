@@ -318,3 +318,45 @@ class BoundaryTables:
                     else:
                         raise ValueError(f"Unknown BC type for turbulence: {kind}")
         self.turb_values = np.concatenate(vals) if vals else np.zeros(0)
+
+    # ---- j-slab view ---------------------------------------------------
+    def slab(self, j_offset, nj_local):
+        """Tables of the rows [j_offset, j_offset + nj_local) for one rank of a j-slab run.
+
+        i_min / i_max tables and masks are sliced; j_min / j_max tables stay (the kernels skip a
+        side that is a cut); the k / omega program keeps only the operations that touch this slab,
+        re-based to local indices.  The pressure reference cell stays in global coordinates (the
+        library resolves the owner)."""
+        import copy
+        if self.per_j:
+            raise NotImplementedError("periodicity along j is not supported across j-slabs")
+        j0, j1 = int(j_offset), int(j_offset) + int(nj_local)
+        if j0 < 0 or j1 > self.nj or nj_local < 1:
+            raise ValueError("slab outside the mesh")
+        first, last = j0 == 0, j1 == self.nj
+        out = copy.copy(self)
+        out.nj = int(nj_local)
+        out.flow = [{k: np.ascontiguousarray(v[j0:j1]) for k, v in t.items()} if side < 2 else t
+                    for side, t in enumerate(self.flow)]
+        out.p_masks = [np.ascontiguousarray(m[j0:j1]) if side < 2 else m for side, m in enumerate(self.p_masks)]
+        ops, vals, off_new = [], [], 0
+        for (op, field, side, lo, hi, off, a) in self.turb_ops:
+            if op in (_lib.TOP_WRAP_I, _lib.TOP_WRAP_J):
+                ops.append((op, field, side, lo, hi, 0, a))
+                continue
+            if side >= 2:
+                if (side == 2 and not first) or (side == 3 and not last):
+                    continue
+                nlo, nhi, src = lo, hi, off
+            else:
+                glo, ghi = max(lo, j0), min(hi, j1 - 1)
+                if glo > ghi:
+                    continue
+                nlo, nhi, src = glo - j0, ghi - j0, off + (glo - lo)
+            n = nhi - nlo + 1
+            vals.append(self.turb_values[src:src + n])
+            ops.append((op, field, side, nlo, nhi, off_new, a))
+            off_new += n
+        out.turb_ops = ops
+        out.turb_values = np.concatenate(vals) if vals else np.zeros(0)
+        return out

@@ -108,14 +108,43 @@ static std::vector<Geo> level_geometry(int ni, int nj) {
     return out;
 }
 
+// j-slab hierarchy: levels [0, l_agg) are slabs of nj_local / 2^l rows (exact 2x coarsening in j so
+// that aggregates never straddle a cut), level l_agg is the first replicated one: the global level
+// (all slabs gathered), coarsened further like a single-rank hierarchy.  Slab levels stop when the
+// slab would drop below 16 rows or an odd row count: below that the exchanges are pure latency.
+static std::vector<Geo> level_geometry_slab(int ni, int nj_loc, int nranks, int rank, int &l_agg, Geo &gs) {
+    std::vector<Geo> out;
+    const int mg_min = 4;
+    Geo g{ni, nj_loc, pitch_for(ni), rank > 0, rank < nranks - 1};
+    out.push_back(g);
+    for (;;) {
+        const Geo f = out.back();
+        const int ci = f.ni > mg_min ? (f.ni + 1) / 2 : f.ni;
+        const int cj = f.nj / 2;                       // f.nj is even by construction
+        if (cj % 2 == 0 && cj >= 16 && (int)out.size() < MAX_LEVELS / 2) {
+            out.push_back(Geo{ci, cj, pitch_for(ci), g.cutlo, g.cuthi});
+            continue;
+        }
+        l_agg = (int)out.size();
+        gs = Geo{ci, cj, pitch_for(ci), 0, 0};
+        const std::vector<Geo> rest = level_geometry(ci, cj * nranks);
+        out.insert(out.end(), rest.begin(), rest.end());
+        break;
+    }
+    return out;
+}
+
 static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 constexpr int N_FINE_PLANES = 12 + 6 + 3 + 4 + 3 + 3 + 2 + 2 + 16 + 3;
 constexpr size_t MISC_BYTES = (size_t)4 * MAX_PARTIALS * sizeof(double) + 4096;
 
-static size_t workspace_bytes_impl(int ni, int nj, size_t bc_bytes) {
-    const std::vector<Geo> lv = level_geometry(ni, nj);
+static size_t workspace_bytes_impl(int ni, int nj, int nranks, size_t bc_bytes) {
+    int l_agg = 0;
+    Geo gs{};
+    const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, 0, l_agg, gs) : level_geometry(ni, nj);
     size_t total = (size_t)N_FINE_PLANES * align256(lv[0].plane_elems() * sizeof(double));
     for (size_t l = 1; l < lv.size(); ++l) total += 6 * align256(lv[l].plane_elems() * sizeof(double));
+    if (nranks > 1) total += 3 * align256(gs.plane_elems() * sizeof(double));
     total += MISC_BYTES + bc_bytes + 4096;
     return total;
 }
@@ -161,17 +190,31 @@ int cfd_version(void) { return 100; }
 
 size_t cfd_workspace_bytes(int ni, int nj) {
     if (ni < 1 || nj < 1) return 0;
-    return workspace_bytes_impl(ni, nj, bc_bytes_for(ni, nj));
+    return workspace_bytes_impl(ni, nj, 1, bc_bytes_for(ni, nj));
+}
+
+size_t cfd_workspace_bytes_slab(int ni, int nj_local, int nranks) {
+    if (ni < 1 || nj_local < 2 || nranks < 1 || (nranks > 1 && nj_local % 2)) return 0;
+    return workspace_bytes_impl(ni, nj_local, nranks, bc_bytes_for(ni, nj_local));
 }
 
 int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes) {
-    if (!out || ni < 1 || nj < 1) { set_error("cfd_create: bad arguments"); return CFD_E_ARG; }
+    return cfd_create_slab(out, ni, nj, device, workspace, workspace_bytes, 0, 1);
+}
+
+int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes, int rank,
+                    int nranks) {
+    if (!out || ni < 1 || nj < 1 || nranks < 1 || rank < 0 || rank >= nranks) { set_error("cfd_create: bad arguments"); return CFD_E_ARG; }
+    if (nranks > 1 && (nj % 2 || nj < 4)) {
+        set_error("j-slab contexts need an even number (>= 4) of local rows, got %d", nj);
+        return CFD_E_ARG;
+    }
     CFD_HIP(hipSetDevice(device));
     cfd_ctx *h = new (std::nothrow) cfd_ctx();
     if (!h) { set_error("out of host memory"); return CFD_E_ARG; }
     Ctx *c = &h->c;
     c->device = device;
-    const size_t need = cfd_workspace_bytes(ni, nj);
+    const size_t need = cfd_workspace_bytes_slab(ni, nj, nranks);
     if (workspace) {
         if (workspace_bytes < need || ((uintptr_t)workspace & 255)) {
             set_error("workspace too small or not 256-byte aligned (need %zu bytes)", need);
@@ -192,7 +235,9 @@ int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_
     e = hipMemsetAsync(c->ws, 0, need, c->stream);
     if (e != hipSuccess) { set_error("hipMemset failed"); return CFD_E_HIP; }
 
-    const std::vector<Geo> lv = level_geometry(ni, nj);
+    Geo gs{};
+    const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, rank, c->l_agg, gs) : level_geometry(ni, nj);
+    c->comm.rank = rank; c->comm.nranks = nranks; c->comm.nj_global = nj * nranks; c->comm.j_offset = rank * nj;
     c->g = lv[0];
     Carver cv{c->ws, 0, need};
     const size_t pb = c->g.plane_elems() * sizeof(double);
@@ -218,6 +263,12 @@ int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_
         const size_t lb = L.g.plane_elems() * sizeof(double);
         L.ci = (double *)cv.take(lb); L.cj = (double *)cv.take(lb); L.D = (double *)cv.take(lb);
         L.x = (double *)cv.take(lb); L.b = (double *)cv.take(lb); L.t = (double *)cv.take(lb);
+        if (nranks > 1 && (int)l == c->l_agg) {
+            L.gs = gs;
+            L.joff = rank * gs.nj;
+            const size_t sb = gs.plane_elems() * sizeof(double);
+            L.s0 = (double *)cv.take(sb); L.s1 = (double *)cv.take(sb); L.s2 = (double *)cv.take(sb);
+        }
     }
     c->partials = (double *)cv.take((size_t)4 * MAX_PARTIALS * sizeof(double));
     c->scal = (double *)cv.take(2048);
@@ -264,6 +315,20 @@ int cfd_destroy(cfd_ctx *ctx) {
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->own_ws && c->ws) hipFree(c->ws);
     delete ctx;
+    return CFD_OK;
+}
+
+int cfd_set_comm(cfd_ctx *ctx, cfd_halo_fn halo, cfd_allreduce_fn allreduce, cfd_allgather_fn allgather, void *user) {
+    CTX(ctx);
+    if (c->comm.nranks > 1 && (!halo || !allreduce || !allgather)) { set_error("cfd_set_comm: null callback"); return CFD_E_ARG; }
+    c->comm.halo = halo; c->comm.allreduce = allreduce; c->comm.allgather = allgather; c->comm.user = user;
+    return CFD_OK;
+}
+
+int cfd_level_info(cfd_ctx *ctx, int *n_levels, int *first_replicated) {
+    CTX(ctx);
+    if (n_levels) *n_levels = (int)c->levels.size();
+    if (first_replicated) *first_replicated = c->l_agg;
     return CFD_OK;
 }
 
@@ -339,6 +404,7 @@ int cfd_upload_mesh(cfd_ctx *ctx, const double *cell_volume, const double *w_rig
 int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node) {
     CTX(ctx);
     if (!node) { set_error("cfd_mesh_from_nodes: null"); return CFD_E_ARG; }
+    if (c->comm.nranks > 1) { set_error("cfd_mesh_from_nodes is single-rank only: upload the slab's metric arrays"); return CFD_E_STATE; }
     const Geo g = c->g;
     // nodes (Ni+1, Nj+1, 2) -> two staging planes [jn][in] via the ghosted-cell transposer
     // (node (a, b) lands at plane index at(a, b)); kry[13], kry[14] hold x and y.
@@ -363,8 +429,17 @@ int cfd_mesh_from_rect(cfd_ctx *ctx, const double *x_nodes, const double *y_node
     const Geo g = c->g;
     double *dx = c->stage_a, *dy = c->stage_a + (g.ni + 8);
     CFD_HIP(hipMemcpyAsync(dx, x_nodes, (size_t)(g.ni + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    CFD_HIP(hipMemcpyAsync(dy, y_nodes, (size_t)(g.nj + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    CFD_TRY(launch_metrics_from_rect(c, dx, dy));
+    if (c->comm.nranks > 1) {
+        // slab: y_nodes starts one node below the slab (the metrics of the cut faces need the
+        // neighbour cell); the face row on a high cut comes from the rank above
+        CFD_HIP(hipMemcpyAsync(dy, y_nodes, (size_t)(g.nj + 3) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CFD_TRY(launch_metrics_from_rect(c, dx, dy + 1));
+        CFD_TRY(halo_exchange(c, g, 1, c->m_wnj, c->m_njx, c->m_njy));
+        CFD_TRY(halo_exchange(c, g, 1, c->m_sj, c->m_dj));
+    } else {
+        CFD_HIP(hipMemcpyAsync(dy, y_nodes, (size_t)(g.nj + 1) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CFD_TRY(launch_metrics_from_rect(c, dx, dy));
+    }
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
     c->p_built = false;
@@ -391,6 +466,18 @@ int cfd_upload_field(cfd_ctx *ctx, int field_id, const double *host, int kind) {
     if (field_id == CFD_F_U) CFD_TRY(launch_copy_plane(c, pl, c->U1()));
     if (field_id == CFD_F_V) CFD_TRY(launch_copy_plane(c, pl, c->V1()));
     if (field_id == CFD_F_P) CFD_TRY(launch_copy_plane(c, pl, c->P1()));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
+
+int cfd_exchange_field(cfd_ctx *ctx, int field_id) {
+    CTX(ctx);
+    double *pl = field_plane(c, field_id);
+    if (!pl) { set_error("cfd_exchange_field: bad field id"); return CFD_E_ARG; }
+    CFD_TRY(halo_exchange(c, c->g, 1, pl));
+    if (field_id == CFD_F_U) CFD_TRY(halo_exchange(c, c->g, 1, c->U1()));
+    if (field_id == CFD_F_V) CFD_TRY(halo_exchange(c, c->g, 1, c->V1()));
+    if (field_id == CFD_F_P) CFD_TRY(halo_exchange(c, c->g, 1, c->P1()));
     CFD_HIP(hipStreamSynchronize(c->stream));
     return CFD_OK;
 }
@@ -460,6 +547,7 @@ int cfd_set_flow_bc(cfd_ctx *ctx, int side, int n, const int32_t *kind_uv, const
 
 int cfd_set_periodicity(cfd_ctx *ctx, int per_i, int per_j, int wrap_p_i, int wrap_p_j) {
     CTX(ctx);
+    if (c->comm.nranks > 1 && (per_j || wrap_p_j)) { set_error("periodicity along j is not supported across j-slabs"); return CFD_E_ARG; }
     c->per_i = per_i ? 1 : 0; c->per_j = per_j ? 1 : 0; c->wrap_p_i = wrap_p_i ? 1 : 0; c->wrap_p_j = wrap_p_j ? 1 : 0;
     return CFD_OK;
 }
@@ -475,7 +563,23 @@ int cfd_set_pressure_bc(cfd_ctx *ctx, const int32_t *mask_imin, const int32_t *m
         else CFD_HIP(hipMemsetAsync(c->pmask[s], 0, n * 4, c->stream));
     }
     CFD_HIP(hipStreamSynchronize(c->stream));
-    if (!has_dirichlet && (pin_i < 0 || pin_i >= c->g.ni || pin_j < 0 || pin_j >= c->g.nj)) {
+    const bool slab = c->comm.nranks > 1;
+    if (slab && per_j) { set_error("periodicity along j is not supported across j-slabs"); return CFD_E_ARG; }
+    // slab runs: pin_j is the global row; the owner pins, everyone else passes it through
+    if (slab && !has_dirichlet) {
+        if (pin_i < 0 || pin_i >= c->g.ni || pin_j < 0 || pin_j >= c->comm.nj_global) {
+            set_error("pressure reference cell (%d, %d) outside the grid", pin_i, pin_j); return CFD_E_ARG;
+        }
+        const int lj = pin_j - c->comm.j_offset;
+        if (lj >= 0 && lj < c->g.nj) {
+            if ((lj == 0 && c->g.cutlo) || (lj == c->g.nj - 1 && c->g.cuthi)) {
+                set_error("pressure reference cell on a slab-cut row (global row %d) is not supported", pin_j); return CFD_E_ARG;
+            }
+            pin_j = lj;
+        } else {
+            pin_i = -1; pin_j = -1;      // not on this rank
+        }
+    } else if (!has_dirichlet && (pin_i < 0 || pin_i >= c->g.ni || pin_j < 0 || pin_j >= c->g.nj)) {
         set_error("pressure reference cell (%d, %d) outside the grid", pin_i, pin_j); return CFD_E_ARG;
     }
     c->pp_per_i = per_i ? 1 : 0; c->pp_per_j = per_j ? 1 : 0; c->has_dirichlet = has_dirichlet ? 1 : 0;
@@ -537,11 +641,19 @@ static int ready(Ctx *c) {
     return CFD_OK;
 }
 
+// physical ghost cells from the BC tables, then (j-slab runs) the cut ghost rows from the neighbours
+static int flow_bc(Ctx *c, double *u, double *v, double *p) {
+    Phase ph(c, PH_BC);
+    CFD_TRY(launch_flow_bc(c, u, v, p));
+    return halo_exchange(c, c->g, 1, u, v, p);
+}
+
 static int do_predictor(Ctx *c, double dt, double res[3]) {
     {
         Phase ph(c, PH_ADV);
         CFD_TRY(launch_eddy_viscosity(c));
         CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+        CFD_TRY(halo_exchange(c, c->g, 1, c->ap));     // Rhie-Chow and d_f read a_P across the cut
         c->dt_ap = dt;
         c->probe_begin(2);
         CFD_TRY(launch_momentum_rhs(c, dt, c->U(), c->V(), c->P()));
@@ -583,8 +695,7 @@ static int do_pressure(Ctx *c, const double *u, const double *v, const double *p
 int cfd_apply_flow_bc(cfd_ctx *ctx) {
     CTX(ctx);
     CFD_TRY(ready(c));
-    Phase ph(c, PH_BC);
-    return launch_flow_bc(c, c->U(), c->V(), c->P());
+    return flow_bc(c, c->U(), c->V(), c->P());
 }
 
 int cfd_compute_dt(cfd_ctx *ctx, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double dt_min,
@@ -607,17 +718,18 @@ int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, dou
     CTX(ctx);
     CFD_TRY(ready(c));
     if (!(dt > 0.0)) { set_error("dt must be positive"); return CFD_E_ARG; }
-    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U(), c->V(), c->P())); }
+    CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
     CFD_TRY(do_predictor(c, dt, res));
-    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U1(), c->V1(), c->P())); }
+    CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P()));
     CFD_TRY(do_pressure(c, c->U1(), c->V1(), c->P()));
     {
         Phase ph(c, PH_CORR);
         CFD_TRY(launch_pcorr_bc(c));
+        CFD_TRY(halo_exchange(c, c->g, 1, c->pcorr));
         CFD_TRY(launch_correct(c, c->U1(), c->V1(), c->U(), c->V(), c->P(), c->U1(), c->V1(), c->P1(), relax_u, relax_v, relax_p));
         c->cur ^= 1;
     }
-    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U(), c->V(), c->P())); }
+    CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
     { Phase ph(c, PH_CONT); CFD_TRY(launch_continuity(c, c->U(), c->V(), c->P(), &res[0])); }
     return CFD_OK;
 }
@@ -627,19 +739,20 @@ int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, dou
     CTX(ctx);
     CFD_TRY(ready(c));
     if (!(dt > 0.0) || n_correctors < 1) { set_error("cfd_piso_step: bad arguments"); return CFD_E_ARG; }
-    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U(), c->V(), c->P())); }
+    CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
     CFD_TRY(do_predictor(c, dt, res));
-    { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U1(), c->V1(), c->P())); }
+    CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P()));
     const double *pcur = c->P();
     for (int n = 0; n < n_correctors; ++n) {
         CFD_TRY(do_pressure(c, c->U1(), c->V1(), pcur));
         {
             Phase ph(c, PH_CORR);
             CFD_TRY(launch_pcorr_bc(c));
+            CFD_TRY(halo_exchange(c, c->g, 1, c->pcorr));
             CFD_TRY(launch_correct(c, c->U1(), c->V1(), c->U(), c->V(), c->P(), c->U1(), c->V1(), c->P1(), relax_u, relax_v, relax_p));
         }
         pcur = c->P1();
-        { Phase ph(c, PH_BC); CFD_TRY(launch_flow_bc(c, c->U1(), c->V1(), c->P1())); }
+        CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P1()));
     }
     c->cur ^= 1;
     { Phase ph(c, PH_CONT); CFD_TRY(launch_continuity(c, c->U(), c->V(), c->P(), &res[0])); }
@@ -652,10 +765,13 @@ int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
     if (!c->turbulent) { set_error("turbulence is disabled"); return CFD_E_STATE; }
     Phase ph(c, PH_TURB);
     CFD_TRY(launch_turb_bc(c));
+    // wall BCs also overwrite interior cells (turbulence.py:304-311): the neighbours' halo rows follow
+    CFD_TRY(halo_exchange(c, c->g, 1, c->k, c->omega));
     CFD_TRY(launch_eddy_viscosity(c));
     CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
     c->dt_ap = dt;
     CFD_TRY(launch_diffusion_ap(c, dt, 0.5, c->ti, c->tj, c->tp));
+    CFD_TRY(halo_exchange(c, c->g, 1, c->ap));
     CFD_TRY(launch_turb_rhs(c, dt));
     const OpDev op{c->ti, c->tj, c->tp, c->g, c->per_i, c->per_j};
     double *b[2] = {c->bu, c->bv}, *x[2] = {c->k, c->omega};
@@ -667,7 +783,7 @@ int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
     CFD_TRY(launch_clip(c, c->k, c->k_clip));
     CFD_TRY(launch_clip(c, c->omega, c->omega_clip));
     CFD_TRY(launch_turb_bc(c));
-    return CFD_OK;
+    return halo_exchange(c, c->g, 1, c->k, c->omega);
 }
 
 int cfd_get_stats(cfd_ctx *ctx, cfd_solve_stats *out) {
@@ -695,6 +811,7 @@ int cfd_momentum_diagonal(cfd_ctx *ctx, double dt, double nut_coef) {
     CTX(ctx);
     NEED_MESH();
     CFD_TRY(launch_diffusion_ap(c, dt, nut_coef, c->ai, c->aj, c->ap));
+    CFD_TRY(halo_exchange(c, c->g, 1, c->ap));
     c->dt_ap = dt;
     return CFD_OK;
 }
@@ -789,6 +906,7 @@ int cfd_correct(cfd_ctx *ctx, double relax_u, double relax_v, double relax_p) {
     CTX(ctx);
     CFD_TRY(ready(c));
     CFD_TRY(launch_pcorr_bc(c));
+    CFD_TRY(halo_exchange(c, c->g, 1, c->pcorr));
     CFD_TRY(launch_correct(c, c->U(), c->V(), c->su, c->sv, c->sp, c->U(), c->V(), c->P(), relax_u, relax_v, relax_p));
     CFD_HIP(hipStreamSynchronize(c->stream));
     return CFD_OK;
@@ -804,6 +922,7 @@ int cfd_apply_turb_bc(cfd_ctx *ctx) {
     CTX(ctx);
     NEED_MESH();
     CFD_TRY(launch_turb_bc(c));
+    CFD_TRY(halo_exchange(c, c->g, 1, c->k, c->omega));
     CFD_HIP(hipStreamSynchronize(c->stream));
     return CFD_OK;
 }

@@ -25,6 +25,12 @@ constexpr int MAX_LEVELS = 24;
 
 struct Geo {
     int ni, nj, pitch;
+    // j-slab decomposition: cutlo / cuthi = 1 when the low / high j edge of this slab is a cut
+    // to a neighbour rank (its ghost rows then hold the neighbour's interior rows, filled by
+    // the halo exchange) instead of a physical boundary.
+    int cutlo, cuthi;
+    __host__ __device__ inline bool blo(int j) const { return j == 0 && !cutlo; }          // physical low-j boundary row
+    __host__ __device__ inline bool bhi(int j) const { return j == nj - 1 && !cuthi; }     // physical high-j boundary row
     // two ghost rows below and above the interior (rows -2, -1 and nj, nj+1): the inner pair is the
     // reference's ghost layer, the outer pair is the extra halo row of the two-sweep fused kernels
     // and of the j-slab exchange.  ghosted index jg = j + 1.
@@ -80,6 +86,23 @@ struct Level {
     Geo g;
     double *ci, *cj, *D;     // operator planes (masked)
     double *x, *b, *t;       // solution, right-hand side, scratch (Jacobi ping-pong)
+    // j-slab runs only, first replicated ("agglomerated") level: this rank's slab of the level
+    // (geometry gs, rows [joff, joff + gs.nj) of the global level) and three slab staging planes
+    // that the distributed level above writes before the all-gather into the global planes.
+    Geo gs{};
+    int joff = 0;
+    double *s0 = nullptr, *s1 = nullptr, *s2 = nullptr;
+};
+
+// j-slab communication: callbacks supplied by the host (torch.distributed over RCCL in
+// production), all of them ordered on Ctx::stream.
+struct Comm {
+    int rank = 0, nranks = 1;
+    int nj_global = 0, j_offset = 0;
+    cfd_halo_fn halo = nullptr;
+    cfd_allreduce_fn allreduce = nullptr;
+    cfd_allgather_fn allgather = nullptr;
+    void *user = nullptr;
 };
 
 // ------------------------------------------------------------------ context
@@ -111,6 +134,8 @@ struct Ctx {
 
     // pressure operator (finest level = levels[0])
     std::vector<Level> levels;
+    int l_agg = 0;               // j-slab runs: first replicated level (levels below it are slabs); 0 = single rank
+    Comm comm;
     bool p_built = false;
     bool p_symmetric = true;
 
@@ -202,7 +227,16 @@ int launch_weighted_sum(Ctx *c, const double *f, const double *w, double out[2])
 int launch_metrics_from_nodes(Ctx *c, const double *xn, const double *yn, int node_pitch);
 int launch_metrics_from_rect(Ctx *c, const double *x1, const double *y1);
 
+// comm.hip -- no-ops on a single rank
+int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b = nullptr, double *d = nullptr);
+int all_reduce(Ctx *c, double *dev, int n, int op);    // op: 0 sum, 1 min
+int all_gather_rows(Ctx *c, const double *src, double *dst, size_t elems_each);
+inline double global_cells(const Ctx *c) {
+    return (double)c->g.ni * (double)(c->comm.nranks > 1 ? c->comm.nj_global : c->g.nj);
+}
+
 // linalg.hip
+int sum_finish(Ctx *c, const double *partials, int nblocks, int nq, double *out);   // + all-reduce over slabs
 int reduce_finish(Ctx *c, int nq, int scal_off);       // partials -> scal[scal_off .. +nq)
 int read_scalars(Ctx *c, int off, int n, double *host);
 int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2], int nb,

@@ -61,11 +61,15 @@ __global__ void k_sum_finish(const double *partials, int n, int nq, double *out)
     }
 }
 
-int reduce_finish(Ctx *c, int nq, int scal_off) {
-    hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, c->stream, c->partials, c->n_red_blocks, nq,
-                       c->scal + scal_off);
+// partials -> out[0..nq), then summed over the slabs of a multi-rank run
+int sum_finish(Ctx *c, const double *partials, int nblocks, int nq, double *out) {
+    hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, c->stream, partials, nblocks, nq, out);
     CFD_HIP(hipGetLastError());
-    return CFD_OK;
+    return all_reduce(c, out, nq, 0);
+}
+
+int reduce_finish(Ctx *c, int nq, int scal_off) {
+    return sum_finish(c, c->partials, c->n_red_blocks, nq, c->scal + scal_off);
 }
 
 int read_scalars(Ctx *c, int off, int n, double *host) {
@@ -101,9 +105,10 @@ __device__ __forceinline__ double offdiag(const OpDev &op, F xf, size_t c, int i
     else if (op.per_i) s += op.ci[c] * xf(c + (g.ni - 1));
     if (i < g.ni - 1) s += op.ci[c + 1] * xf(c + 1);
     else if (op.per_i) s += op.ci[c + 1] * xf(c - (g.ni - 1));
-    if (j > 0) s += op.cj[c] * xf(c - P);
+    // at a slab cut the ghost row holds the neighbour rank's row (halo exchange)
+    if (j > 0 || g.cutlo) s += op.cj[c] * xf(c - P);
     else if (op.per_j) s += op.cj[c] * xf(c + (size_t)(g.nj - 1) * P);
-    if (j < g.nj - 1) s += op.cj[c + P] * xf(c + P);
+    if (j < g.nj - 1 || g.cuthi) s += op.cj[c + P] * xf(c + P);
     else if (op.per_j) s += op.cj[c + P] * xf(c - (size_t)(g.nj - 1) * P);
     return s;
 }
@@ -372,6 +377,7 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
         return o;
     };
     hipLaunchKernelGGL(k_inv_diag, grid, blk, 0, st, g, T, op.D, inv);
+    CFD_TRY(halo_exchange(c, g, 1, inv));
     CFD_HIP(hipMemsetAsync(S, 0, sizeof(BiScal), st));
     double bb[2] = {0, 0}, rr[2] = {0, 0};
     if (x0) {
@@ -406,6 +412,7 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
     while (n_active > 0 && it < maxiter) {
         const int gen = it & 1;
         hipLaunchKernelGGL((k_bi_p<NB>), grid, blk, 0, st, g, T, S, gen, it == 0, act, cv(r), cv(v), p);
+        CFD_TRY(halo_exchange(c, g, 1, p.p[0], NB == 2 ? p.p[NB - 1] : nullptr));
         if (NB == 2) c->probe_begin(3);
         hipLaunchKernelGGL((k_bi_apply<NB, true, 0>), grid, blk, 0, st, op, T, inv, act, cv(p), cv(p), cv(rh), v,
                            c->partials);
@@ -413,6 +420,7 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, NB, OFF_OF(sigma[0])));
         hipLaunchKernelGGL((k_bi_s<NB>), grid, blk, 0, st, g, T, S, gen, act, cv(v), r);
+        CFD_TRY(halo_exchange(c, g, 1, r.p[0], NB == 2 ? r.p[NB - 1] : nullptr));
         hipLaunchKernelGGL((k_bi_apply<NB, true, 1>), grid, blk, 0, st, op, T, inv, act, cv(r), cv(r), cv(r), t,
                            c->partials);
         CFD_HIP(hipGetLastError());
@@ -422,8 +430,7 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
             CFD_TRY(reduce_finish(c, 4, OFF_OF(ts[0])));
         } else {
             CFD_TRY(reduce_finish(c, 1, OFF_OF(ts[0])));
-            hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, st, c->partials + MAX_PARTIALS, T.blocks, 1,
-                               c->scal + OFF_OF(tt[0]));
+            CFD_TRY(sum_finish(c, c->partials + MAX_PARTIALS, T.blocks, 1, c->scal + OFF_OF(tt[0])));
         }
         hipLaunchKernelGGL((k_bi_x<NB, true>), grid, blk, 0, st, g, T, S, gen, inv, act, cv(p), cv(p), cv(p), cv(t),
                            cv(rh), r, xv, c->partials);
@@ -431,9 +438,7 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
         // (rhat, r) -> rho[gen^1][q] ; (r, r) -> rr[q]
         c->n_red_blocks = T.blocks;
         CFD_TRY(reduce_finish(c, NB, OFF_OF(rho[gen ^ 1][0])));
-        hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, st, c->partials + (size_t)NB * MAX_PARTIALS, T.blocks, NB,
-                           c->scal + OFF_OF(rr[0]));
-        CFD_HIP(hipGetLastError());
+        CFD_TRY(sum_finish(c, c->partials + (size_t)NB * MAX_PARTIALS, T.blocks, NB, c->scal + OFF_OF(rr[0])));
         ++it;
         double got[2];
         CFD_TRY(read_scalars(c, OFF_OF(rr[0]), NB, got));
@@ -452,12 +457,13 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
     if (rms) {
         CVecs<NB> xc;
         for (int q = 0; q < NB; ++q) xc.p[q] = x[q];
+        CFD_TRY(halo_exchange(c, g, 1, x[0], NB == 2 ? x[NB - 1] : nullptr));
         hipLaunchKernelGGL((k_resid_norm<NB>), grid, blk, 0, st, op, T, xc, bc, c->partials);
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, NB, 0));
         double s2[2];
         CFD_TRY(read_scalars(c, 0, NB, s2));
-        for (int q = 0; q < NB; ++q) rms[q] = sqrt(s2[q] / ((double)g.ni * (double)g.nj));
+        for (int q = 0; q < NB; ++q) rms[q] = sqrt(s2[q] / global_cells(c));
     }
     return CFD_OK;
 }
@@ -604,11 +610,13 @@ __device__ __forceinline__ int wrap_index(int v, int n, int per) {
     v %= n;
     return v < 0 ? v + n : v;
 }
-// rows leave the domain by at most a few cells: one conditional add / subtract is enough
-__device__ __forceinline__ int wrap_row(int j, int n, int per) {
-    if (j >= 0 && j < n) return j;
-    if (!per) return -1;
-    return j < 0 ? j + n : j - n;
+// plane row (= j + 2) that holds logical row j, or -1 when the row lies outside the domain.
+// Rows leave the slab by at most two cells: across a slab cut they are the halo rows, across a
+// periodic seam one conditional add / subtract wraps them.
+__device__ __forceinline__ int mem_row(int j, const Geo &g, int per) {
+    if (j >= 0 && j < g.nj) return j + 2;
+    if (j < 0) return g.cutlo ? j + 2 : (per ? j + g.nj + 2 : -1);
+    return g.cuthi ? j + 2 : (per ? j - g.nj + 2 : -1);
 }
 
 // 1/d without the IEEE division sequence: v_rcp_f64 + two Newton steps (the V-cycle is a
@@ -634,9 +642,10 @@ __device__ __forceinline__ double lane_right(double v) {
 
 // Unconditional loads from a clamped (always valid) cell: lanes / rows outside the domain
 // read finite garbage that only ever multiplies x = 0.
-__device__ __forceinline__ RowC load_rowc(const OpDev &op, const double *b, size_t c) {
+// `up` = distance to the row above (0 for the outermost halo row, whose north face is never used).
+__device__ __forceinline__ RowC load_rowc(const OpDev &op, const double *b, size_t c, size_t up) {
     RowC r;
-    r.b = b[c]; r.d = op.D[c]; r.cw = op.ci[c]; r.ce = op.ci[c + 1]; r.cs = op.cj[c]; r.cn = op.cj[c + op.g.pitch];
+    r.b = b[c]; r.d = op.D[c]; r.cw = op.ci[c]; r.ce = op.ci[c + 1]; r.cs = op.cj[c]; r.cn = op.cj[c + up];
     r.inv = fast_rcp(r.d);
     return r;
 }
@@ -680,9 +689,9 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
         const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         auto rowc = [&](int j, bool &valid) -> RowC {
-            const int jm = wrap_row(j, g.nj, op.per_j);
-            valid = cvalid && jm >= 0;
-            return load_rowc(op, b, (size_t)(max(jm, 0) + 2) * P + colo);
+            const int mr = mem_row(j, g, op.per_j);
+            valid = cvalid && mr >= 0;
+            return load_rowc(op, b, (size_t)(mr >= 0 ? mr : 2) * P + colo, mr < g.nj + 3 ? P : 0);
         };
         bool v2, v1;
         RowC rc2 = rowc(j0 - 2, v2);
@@ -741,13 +750,13 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const doub
         const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         auto rowc = [&](int j, bool &valid, double &x0) -> RowC {
-            const int jm = wrap_row(j, g.nj, op.per_j);
-            valid = cvalid && jm >= 0;
-            const int js = max(jm, 0);
+            const int mr = mem_row(j, g, op.per_j);
+            valid = cvalid && mr >= 0;
+            const int js = (mr >= 0 ? mr : 2) - 2;     // -2, -1 / nj, nj+1 are halo rows at a slab cut
             const size_t c = (size_t)(js + 2) * P + colo;
             const double xv = x[c] + e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
             x0 = valid ? xv : 0.0;
-            return load_rowc(op, b, c);
+            return load_rowc(op, b, c, mr < g.nj + 3 ? P : 0);
         };
         bool v2, v1;
         double x0a, x0b, x0c;
@@ -791,9 +800,9 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const doub
     }
 }
 
-static inline bool level_fusable(const Ctx *c, const Level &F, const Level &C) {
-    return c->mg_fused && c->mg_pre == 2 && c->mg_post == 2 && F.g.ni >= 16 && F.g.nj >= 16 &&
-           C.g.ni == (F.g.ni + 1) / 2 && C.g.nj == (F.g.nj + 1) / 2;
+static inline bool level_fusable(const Ctx *c, const Geo &F, const Geo &C) {
+    return c->mg_fused && c->mg_pre == 2 && c->mg_post == 2 && F.ni >= 16 && F.nj >= 16 &&
+           C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
 }
 static inline int march_blocks(const MarchGeo &m) {
     const long items = (long)m.nstrips * m.nsegs;
@@ -804,9 +813,13 @@ static inline int march_blocks(const MarchGeo &m) {
 static inline OpDev level_op(const Ctx *c, const Level &L) {
     return OpDev{L.ci, L.cj, L.D, L.g, c->pp_per_i, c->pp_per_j};
 }
-static inline void factors(const Level &f, const Level &co, int &fi, int &fj) {
-    fi = (co.g.ni == f.g.ni) ? 1 : 2;
-    fj = (co.g.nj == f.g.nj) ? 1 : 2;
+static inline void factors(const Geo &f, const Geo &co, int &fi, int &fj) {
+    fi = (co.ni == f.ni) ? 1 : 2;
+    fj = (co.nj == f.nj) ? 1 : 2;
+}
+// geometry the level above sees of level C: this rank's slab of it when C is the first replicated level
+static inline Geo coarse_view(const Ctx *c, int lc) {
+    return (c->l_agg > 0 && lc == c->l_agg) ? c->levels[lc].gs : c->levels[lc].g;
 }
 
 // asymmetry probe: partial[0] = max |ci[0,j] - ci[Ni,j]| etc. (sum of abs differences is enough)
@@ -838,16 +851,34 @@ int build_pressure_hierarchy(Ctx *c) {
     Level &L0 = c->levels[0];
     CFD_TRY(launch_pressure_coeffs(c, L0));
     hipStream_t st = c->stream;
-    for (size_t l = 0; l + 1 < c->levels.size(); ++l) {
+    const int la = c->l_agg;
+    CFD_TRY(halo_exchange(c, L0.g, 2, L0.ci, L0.cj, L0.D));
+    for (int l = 0; l + 1 < (int)c->levels.size(); ++l) {
         Level &F = c->levels[l], &C = c->levels[l + 1];
+        const bool to_agg = la > 0 && l + 1 == la;
+        const Geo cg = coarse_view(c, l + 1);
+        double *ci_t = to_agg ? C.s0 : C.ci, *cj_t = to_agg ? C.s1 : C.cj, *D_t = to_agg ? C.s2 : C.D;
         int fi, fj;
-        factors(F, C, fi, fj);
-        const Tiling Tc = tiling(C.g);
+        factors(F.g, cg, fi, fj);
+        const Tiling Tc = tiling(cg);
         // C.t is used as the scratch for the diagonal extra
-        hipLaunchKernelGGL(k_mg_coarsen, dim3(Tc.blocks), block2d(), 0, st, F.g, F.ci, F.cj, F.D, C.g, Tc, fi, fj, C.ci,
-                           C.cj, C.t);
-        hipLaunchKernelGGL(k_mg_coarse_diag, dim3(Tc.blocks), block2d(), 0, st, C.g, Tc, C.ci, C.cj, C.t, C.D);
+        hipLaunchKernelGGL(k_mg_coarsen, dim3(Tc.blocks), block2d(), 0, st, F.g, F.ci, F.cj, F.D, cg, Tc, fi, fj, ci_t,
+                           cj_t, C.t);
+        hipLaunchKernelGGL(k_mg_coarse_diag, dim3(Tc.blocks), block2d(), 0, st, cg, Tc, ci_t, cj_t, C.t, D_t);
         CFD_HIP(hipGetLastError());
+        if (to_agg) {
+            // replicate the level: every rank gathers all slabs, the top boundary face row of c_j
+            // comes from the last rank (gathered through the scratch plane)
+            const size_t P = cg.pitch, rows = (size_t)cg.nj * P;
+            CFD_TRY(all_gather_rows(c, ci_t + 2 * P, C.ci + 2 * P, rows));
+            CFD_TRY(all_gather_rows(c, cj_t + 2 * P, C.cj + 2 * P, rows));
+            CFD_TRY(all_gather_rows(c, D_t + 2 * P, C.D + 2 * P, rows));
+            CFD_TRY(all_gather_rows(c, cj_t + (size_t)(2 + cg.nj) * P, C.t + 2 * P, P));
+            CFD_HIP(hipMemcpyAsync(C.cj + (size_t)(2 + C.g.nj) * P, C.t + (size_t)(2 + c->comm.nranks - 1) * P,
+                                   P * sizeof(double), hipMemcpyDeviceToDevice, st));
+        } else if (l + 1 < la) {
+            CFD_TRY(halo_exchange(c, C.g, 2, C.ci, C.cj, C.D));
+        }
     }
     c->p_symmetric = true;
     if (c->pp_per_i || c->pp_per_j) {
@@ -855,6 +886,7 @@ int build_pressure_hierarchy(Ctx *c) {
                            c->scal + 8);
         CFD_HIP(hipGetLastError());
         double a[2];
+        CFD_TRY(all_reduce(c, c->scal + 8, 2, 0));
         CFD_TRY(read_scalars(c, 8, 2, a));
         c->p_symmetric = !(a[0] > 1.0e-13 * a[1]);
     }
@@ -876,34 +908,42 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         oth[l] = (l == 0) ? z1 : c->levels[l].t;
         rhs[l] = (l == 0) ? r : c->levels[l].b;
     }
+    const int la = c->l_agg;   // levels [0, la) are j-slabs with halo exchange, the rest is replicated
     for (int l = 0; l < nl - 1; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
         const OpDev op = level_op(c, L);
-        if (level_fusable(c, L, C)) {
+        const bool to_agg = la > 0 && l + 1 == la;
+        const Geo cg = coarse_view(c, l + 1);
+        double *cb = to_agg ? C.s0 : C.b;
+        if (level_fusable(c, L.g, cg)) {
             const MarchGeo mgeo = march_geo(L.g);
             const dim3 grid(march_blocks(mgeo));
+            CFD_TRY(halo_exchange(c, L.g, 2, const_cast<double *>(rhs[l])));
             if (l == 0) {
                 c->probe_begin(1);
-                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], C.g, C.b);
+                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], cg, cb);
                 c->probe_end(1);
             } else {
-                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], C.g, C.b);
+                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], cg, cb);
             }
             CFD_HIP(hipGetLastError());
-            continue;
+        } else {
+            const Tiling T = tiling(L.g);
+            hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
+            for (int s = 1; s < pre; ++s) {
+                CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
+                hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
+                std::swap(cur[l], oth[l]);
+            }
+            CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
+            int fi, fj;
+            factors(L.g, cg, fi, fj);
+            const Tiling Tc = tiling(cg);
+            hipLaunchKernelGGL(k_mg_restrict, dim3(Tc.blocks), block2d(), 0, st, op, rhs[l], cur[l], cg, Tc, fi, fj, cb);
+            CFD_HIP(hipGetLastError());
         }
-        const Tiling T = tiling(L.g);
-        hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
-        for (int s = 1; s < pre; ++s) {
-            hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
-            std::swap(cur[l], oth[l]);
-        }
-        int fi, fj;
-        factors(L, C, fi, fj);
-        const Tiling Tc = tiling(C.g);
-        hipLaunchKernelGGL(k_mg_restrict, dim3(Tc.blocks), block2d(), 0, st, op, rhs[l], cur[l], C.g, Tc, fi, fj, C.b);
-        CFD_HIP(hipGetLastError());
+        if (to_agg) CFD_TRY(all_gather_rows(c, cb + 2 * (size_t)cg.pitch, C.b + 2 * (size_t)cg.pitch, (size_t)cg.nj * cg.pitch));
     }
     {
         const Level &L = c->levels[nl - 1];
@@ -927,17 +967,24 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
         const OpDev op = level_op(c, L);
-        if (level_fusable(c, L, C)) {
+        const Geo cg = coarse_view(c, l + 1);
+        // coarse correction as this level sees it: its own slab rows of the replicated plane
+        // (whose neighbouring rows are the halo), or the exchanged slab plane
+        const double *e = cur[l + 1];
+        if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
+        else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, 1, cur[l + 1]));
+        if (level_fusable(c, L.g, cg)) {
             const MarchGeo mgeo = march_geo(L.g);
             const dim3 grid(march_blocks(mgeo));
+            CFD_TRY(halo_exchange(c, L.g, 2, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
-                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], C.g, cur[l + 1], om,
+                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om,
                                    oth[l], c->partials);
                 c->probe_end(7);
                 *dot_blocks = (int)grid.x;
             } else {
-                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], C.g, cur[l + 1], om,
+                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om,
                                    oth[l], c->partials);
             }
             std::swap(cur[l], oth[l]);
@@ -946,9 +993,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         }
         const Tiling T = tiling(L.g);
         int fi, fj;
-        factors(L, C, fi, fj);
-        hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, C.g, fi, fj, cur[l + 1], cur[l]);
+        factors(L.g, cg, fi, fj);
+        hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, cg, fi, fj, e, cur[l]);
         for (int s = 0; s < post; ++s) {
+            CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
             hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
             std::swap(cur[l], oth[l]);
         }
@@ -1061,6 +1109,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rz[gen])));
         }
         hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);
+        CFD_TRY(halo_exchange(c, g, 1, p));
         c->probe_begin(0);
         hipLaunchKernelGGL(k_cg_q, grid, blk, 0, st, op, T, p, q, c->partials);
         c->probe_end(0);
@@ -1112,6 +1161,7 @@ static int bicgstab_mg(Ctx *c, const double *b, double *x, double tol, int maxit
         int db = 0;
         CFD_TRY(vcycle_impl(c, p.p[0], w0, w1, &out, &db));
         CFD_HIP(hipMemcpyAsync(ph, out, g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+        CFD_TRY(halo_exchange(c, g, 1, ph));
         hipLaunchKernelGGL((k_bi_apply<1, false, 0>), grid, blk, 0, st, op, T, (const double *)nullptr, act, cv(p),
                            CVecs<1>{{ph}}, cv(rh), v, c->partials);
         CFD_HIP(hipGetLastError());
@@ -1119,21 +1169,19 @@ static int bicgstab_mg(Ctx *c, const double *b, double *x, double tol, int maxit
         hipLaunchKernelGGL((k_bi_s<1>), grid, blk, 0, st, g, T, S, gen, act, cv(v), r);
         CFD_TRY(vcycle_impl(c, r.p[0], w0, w1, &out, &db));
         CFD_HIP(hipMemcpyAsync(sh, out, g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+        CFD_TRY(halo_exchange(c, g, 1, sh));
         hipLaunchKernelGGL((k_bi_apply<1, false, 1>), grid, blk, 0, st, op, T, (const double *)nullptr, act, cv(r),
                            CVecs<1>{{sh}}, cv(r), t, c->partials);
         CFD_HIP(hipGetLastError());
         c->n_red_blocks = T.blocks;
         CFD_TRY(reduce_finish(c, 1, OFF_OF(ts[0])));
-        hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, st, c->partials + MAX_PARTIALS, T.blocks, 1,
-                           c->scal + OFF_OF(tt[0]));
+        CFD_TRY(sum_finish(c, c->partials + MAX_PARTIALS, T.blocks, 1, c->scal + OFF_OF(tt[0])));
         hipLaunchKernelGGL((k_bi_x<1, false>), grid, blk, 0, st, g, T, S, gen, (const double *)nullptr, act, cv(p),
                            CVecs<1>{{ph}}, CVecs<1>{{sh}}, cv(t), cv(rh), r, xv, c->partials);
         CFD_HIP(hipGetLastError());
         c->n_red_blocks = T.blocks;
         CFD_TRY(reduce_finish(c, 1, OFF_OF(rho[gen ^ 1][0])));
-        hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, st, c->partials + MAX_PARTIALS, T.blocks, 1,
-                           c->scal + OFF_OF(rr[0]));
-        CFD_HIP(hipGetLastError());
+        CFD_TRY(sum_finish(c, c->partials + MAX_PARTIALS, T.blocks, 1, c->scal + OFF_OF(rr[0])));
         ++it;
         CFD_TRY(read_scalars(c, OFF_OF(rr[0]), 1, &rr));
         if (!(rr == rr)) { set_error("MG-BiCGStab: non-finite residual at iteration %d", it); return CFD_E_NUMERIC; }
@@ -1174,7 +1222,7 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                 case 1: {
                     if (!c->p_built) { set_error("pressure operator not built"); return CFD_E_STATE; }
                     const OpDev op = level_op(c, c->levels[0]);
-                    if (c->levels.size() > 1 && level_fusable(c, c->levels[0], c->levels[1])) {
+                    if (c->levels.size() > 1 && level_fusable(c, c->levels[0].g, coarse_view(c, 1))) {
                         const MarchGeo mgeo = march_geo(g);
                         hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->kry[1],
                                            c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_omega, c->kry[5], c->partials);
@@ -1199,7 +1247,7 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                     if (!c->p_built || c->levels.size() < 2) { set_error("no coarse level"); return CFD_E_STATE; }
                     const Level &L = c->levels[0], &C = c->levels[1];
                     int fi, fj;
-                    factors(L, C, fi, fj);
+                    factors(L.g, C.g, fi, fj);
                     const Tiling Tc = tiling(C.g);
                     hipLaunchKernelGGL(k_mg_restrict, dim3(Tc.blocks), blk, 0, st, level_op(c, L), c->kry[1], c->kry[4],
                                        C.g, Tc, fi, fj, C.b);

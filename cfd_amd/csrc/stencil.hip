@@ -166,7 +166,7 @@ __global__ void k_diffusion_ap(Geo g, MeshDev m, const double *nut, double nu, d
     if (i == g.ni - 1) ai[c + 1] = ae;
     // south
     nf = nuP;
-    if (j > 0) {
+    if (!g.blo(j)) {
         const double wn = m.wnj[c];
         nf = (1.0 - wn) * (nu + coef * nut[c - P]) + wn * nuP;
     }
@@ -174,7 +174,7 @@ __global__ void k_diffusion_ap(Geo g, MeshDev m, const double *nut, double nu, d
     aj[c] = as;
     // north
     nf = nuP;
-    if (j < g.nj - 1) {
+    if (!g.bhi(j)) {
         const double wn = m.wnj[c + P];
         nf = (1.0 - wn) * nuP + wn * (nu + coef * nut[c + P]);
     }
@@ -206,6 +206,7 @@ __global__ void k_flow_bc(Geo g, FlowBCDev bc, double *u, double *v, double *p, 
     const int n = (side < 2) ? g.nj : g.ni;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if ((side == CFD_SIDE_JMIN && g.cutlo) || (side == CFD_SIDE_JMAX && g.cuthi)) return;   // slab cut: halo exchange
     const FlowBCSide &s = bc.side[side];
     if (s.n != n) return;   // table not set
     size_t cin, cgh, cop;    // interior cell, its ghost, the interior cell on the opposite side
@@ -371,6 +372,7 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
                        cfl, use_cfl_diff, cfl_diff, c->partials, tx, tiles);
     CFD_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials, nb, 2, c->scal);
+    CFD_TRY(all_reduce(c, c->scal, 2, 1));    // global minimum over the slabs
     CFD_HIP(hipGetLastError());
     return read_scalars(c, 0, 2, out);
 }
@@ -388,7 +390,7 @@ __global__ void k_momentum_rhs(Geo g, MeshDev m, FluxIn f, const double *kgrad, 
     const int P = g.pitch;
     const size_t c = g.cell(i, j);
     const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
-    const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+    const double fs = flux_j(f, m, c, P, g.blo(j), false), fn = flux_j(f, m, c + P, P, false, g.bhi(j));
     const double vol = m.vol[c];
     const double advu = upwind(f.u, c, P, fw, fe, fs, fn, vol);
     const double advv = upwind(f.v, c, P, fw, fe, fs, fn, vol);
@@ -409,8 +411,8 @@ __global__ void k_momentum_rhs(Geo g, MeshDev m, FluxIn f, const double *kgrad, 
         if (i == g.ni - 1) { b_u += ai[c + 1] * f.u[c + 1]; b_v += ai[c + 1] * f.v[c + 1]; }
     }
     if (!per_j) {
-        if (j == 0) { b_u += aj[c] * f.u[c - P]; b_v += aj[c] * f.v[c - P]; }
-        if (j == g.nj - 1) { b_u += aj[c + P] * f.u[c + P]; b_v += aj[c + P] * f.v[c + P]; }
+        if (g.blo(j)) { b_u += aj[c] * f.u[c - P]; b_v += aj[c] * f.v[c - P]; }
+        if (g.bhi(j)) { b_u += aj[c + P] * f.u[c + P]; b_v += aj[c + P] * f.v[c + P]; }
     }
     bu[c] = b_u;
     bv[c] = b_v;
@@ -438,7 +440,7 @@ __global__ void k_turb_rhs(Geo g, MeshDev m, FluxIn f, const double *om, const d
     const int P = g.pitch;
     const size_t c = g.cell(i, j);
     const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
-    const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+    const double fs = flux_j(f, m, c, P, g.blo(j), false), fn = flux_j(f, m, c + P, P, false, g.bhi(j));
     const double vol = m.vol[c];
     const double *k = f.k;
     const double advk = upwind(k, c, P, fw, fe, fs, fn, vol);
@@ -458,8 +460,8 @@ __global__ void k_turb_rhs(Geo g, MeshDev m, FluxIn f, const double *om, const d
         if (i == g.ni - 1) { b_k += ti[c + 1] * k[c + 1]; b_w += ti[c + 1] * om[c + 1]; }
     }
     if (!per_j) {
-        if (j == 0) { b_k += tj[c] * k[c - P]; b_w += tj[c] * om[c - P]; }
-        if (j == g.nj - 1) { b_k += tj[c + P] * k[c + P]; b_w += tj[c + P] * om[c + P]; }
+        if (g.blo(j)) { b_k += tj[c] * k[c - P]; b_w += tj[c] * om[c - P]; }
+        if (g.bhi(j)) { b_k += tj[c + P] * k[c + P]; b_w += tj[c + P] * om[c + P]; }
     }
     bk[c] = b_k;
     bw[c] = b_w;
@@ -482,7 +484,7 @@ __global__ void k_pressure_rhs(Geo g, MeshDev m, FluxIn f, double *b) {
     const int P = g.pitch;
     const size_t c = g.cell(i, j);
     const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
-    const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+    const double fs = flux_j(f, m, c, P, g.blo(j), false), fn = flux_j(f, m, c + P, P, false, g.bhi(j));
     const double vol = m.vol[c];
     const double div = (fe - fw + fn - fs) / vol;
     b[c] = vol * (-div);
@@ -511,7 +513,7 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
     hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
     CFD_HIP(hipGetLastError());
-    if (!c->has_dirichlet) {
+    if (!c->has_dirichlet && c->pin_i >= 0) {      // pin_i < 0: the reference cell lives on another slab
         const Level &L = c->levels[0];
         hipLaunchKernelGGL(k_pin_rhs, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->pin_value,
                            c->scal + 64, L.D, c->pp_per_i, c->pp_per_j, b);
@@ -550,15 +552,15 @@ __global__ void k_pressure_coeffs(Geo g, MeshDev m, const double *ap, PMasks pm,
     const int P = g.pitch;
     const size_t c = g.cell(i, j);
     const double dw = dcoef_i(m, ap, c, i == 0, false), de = dcoef_i(m, ap, c + 1, false, i == g.ni - 1);
-    const double ds = dcoef_j(m, ap, c, P, j == 0, false), dn = dcoef_j(m, ap, c + P, P, false, j == g.nj - 1);
+    const double ds = dcoef_j(m, ap, c, P, g.blo(j), false), dn = dcoef_j(m, ap, c + P, P, false, g.bhi(j));
     double aw = dw, ae = de, as = ds, an = dn;
     if (!per_i) {
         if (i == 0) aw = (pm.m[0] && pm.m[0][j]) ? 2.0 * dw : 0.0;
         if (i == g.ni - 1) ae = (pm.m[1] && pm.m[1][j]) ? 2.0 * de : 0.0;
     }
     if (!per_j) {
-        if (j == 0) as = (pm.m[2] && pm.m[2][i]) ? 2.0 * ds : 0.0;
-        if (j == g.nj - 1) an = (pm.m[3] && pm.m[3][i]) ? 2.0 * dn : 0.0;
+        if (g.blo(j)) as = (pm.m[2] && pm.m[2][i]) ? 2.0 * ds : 0.0;
+        if (g.bhi(j)) an = (pm.m[3] && pm.m[3][i]) ? 2.0 * dn : 0.0;
     }
     D[c] = aw + ae + as + an;
     // face planes keep the boundary-face value too (2 d_f Dirichlet / 0 Neumann): the
@@ -593,7 +595,7 @@ int launch_pressure_coeffs(Ctx *c, Level &L) {
     hipLaunchKernelGGL(k_pressure_coeffs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->ap, pm,
                        c->pp_per_i, c->pp_per_j, L.ci, L.cj, L.D);
     CFD_HIP(hipGetLastError());
-    if (!c->has_dirichlet) {
+    if (!c->has_dirichlet && c->pin_i >= 0) {
         hipLaunchKernelGGL(k_pin_operator, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->pp_per_i,
                            c->pp_per_j, L.ci, L.cj, c->scal + 64);
         CFD_HIP(hipGetLastError());
@@ -606,6 +608,7 @@ int launch_pressure_coeffs(Ctx *c, Level &L) {
 // ----------------------------------------------------------------------------------
 __global__ void k_pcorr_bc(Geo g, PMasks pm, int per_i, int per_j, double *pc) {
     const int side = blockIdx.y;
+    if ((side == CFD_SIDE_JMIN && g.cutlo) || (side == CFD_SIDE_JMAX && g.cuthi)) return;
     const int n = (side < 2) ? g.nj : g.ni;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
@@ -675,7 +678,7 @@ __global__ void k_continuity(Geo g, MeshDev m, FluxIn f, double *partials, int t
         const int P = g.pitch;
         const size_t c = g.cell(i, j);
         const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
-        const double fs = flux_j(f, m, c, P, j == 0, false), fn = flux_j(f, m, c + P, P, false, j == g.nj - 1);
+        const double fs = flux_j(f, m, c, P, g.blo(j), false), fn = flux_j(f, m, c + P, P, false, g.bhi(j));
         const double div = (fe - fw + fn - fs) / m.vol[c];
         acc += div * div;
     }
@@ -693,7 +696,7 @@ int launch_continuity(Ctx *c, const double *u, const double *v, const double *p,
     CFD_TRY(reduce_finish(c, 1, 0));
     double s;
     CFD_TRY(read_scalars(c, 0, 1, &s));
-    *out = sqrt(s / ((double)c->g.ni * (double)c->g.nj));
+    *out = sqrt(s / global_cells(c));
     return CFD_OK;
 }
 
@@ -735,8 +738,8 @@ __global__ void k_face_flux(Geo g, MeshDev m, FluxIn f, double *fi, double *fj) 
     const size_t c = g.cell(i, j);
     fi[c] = flux_i(f, m, c, i == 0, false);
     if (i == g.ni - 1) fi[c + 1] = flux_i(f, m, c + 1, false, true);
-    fj[c] = flux_j(f, m, c, P, j == 0, false);
-    if (j == g.nj - 1) fj[c + P] = flux_j(f, m, c + P, P, false, true);
+    fj[c] = flux_j(f, m, c, P, g.blo(j), false);
+    if (j == g.nj - 1) fj[c + P] = flux_j(f, m, c + P, P, false, !g.cuthi);
 }
 
 int launch_face_flux(Ctx *c, const double *u, const double *v, const double *p, int rc, int use_peff, double *fi,
@@ -892,11 +895,11 @@ __device__ void metrics_cell(Geo g, NodeFn nd, MeshOut o, int i, int j) {
         const double ux = nx / sn, uy = ny / sn;
         const double fx = 0.5 * (a.x + b.x), fy = 0.5 * (a.y + b.y);
         double dd, wn = 0.5;
-        if (j == 0) {
+        if (g.blo(j)) {
             dd = 2.0 * fabs((cx - fx) * ux + (cy - fy) * uy);
         } else {
             double lx, ly, lv;
-            cell_centroid(nd, i, j - 1, lx, ly, lv);
+            cell_centroid(nd, i, j - 1, lx, ly, lv);     // at a slab cut the node row -1 is the halo row
             wn = interp_t(lx, ly, cx, cy, fx, fy);
             dd = fabs((cx - lx) * ux + (cy - ly) * uy);
         }

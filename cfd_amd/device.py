@@ -24,6 +24,19 @@ class Device:
                                   int(workspace_bytes)))
         self.turbulent = False
 
+    # j-slab attributes (cfd_amd.slab.slab_device overrides them on a multi-rank run): this
+    # context holds rows [j_offset, j_offset + nj) of a mesh with nj_global rows.
+    rank, nranks, j_offset = 0, 1, 0
+    comm = None
+
+    @property
+    def nj_global(self):
+        return self.__dict__.get("_nj_global", self.nj)
+
+    @nj_global.setter
+    def nj_global(self, v):
+        self._nj_global = int(v)
+
     def close(self):
         if self._h:
             self.lib.cfd_destroy(self._h)
@@ -36,8 +49,8 @@ class Device:
             pass
 
     # ---------------------------------------------------------------- shapes
-    def shape(self, kind):
-        ni, nj = self.ni, self.nj
+    def shape(self, kind, whole=False):
+        ni, nj = self.ni, (self.nj_global if whole else self.nj)
         return {(_lib.KIND_GHOSTED): (ni + 2, nj + 2), (_lib.KIND_CELL): (ni, nj),
                 (_lib.KIND_FACE_I): (ni + 1, nj), (_lib.KIND_FACE_J): (ni, nj + 1)}[kind]
 
@@ -48,6 +61,9 @@ class Device:
         if not (np.array_equal(wl, 1.0 - wr) and np.array_equal(ws, 1.0 - wn)):
             raise ValueError("mesh interpolation weights are not complementary (w_left != 1 - w_right); "
                              "regenerate the mesh with precompute_from_nodes")
+        if self.nranks > 1 and np.asarray(mesh["cell_volume"]).shape == (self.ni, self.nj_global):
+            from .slab import slab_mesh
+            mesh = slab_mesh(mesh, self.j_offset, self.nj)
         arrs = [_f64(mesh[k]) for k in ("cell_volume", "w_right_i", "w_north_j", "face_normal_i",
                                         "face_normal_j", "diff_d_i", "diff_d_j", "cell_spacing_i",
                                         "cell_spacing_j")]
@@ -62,9 +78,14 @@ class Device:
         check(self.lib.cfd_mesh_from_nodes(self._h, dptr(node)))
 
     def mesh_from_rect(self, x_nodes, y_nodes):
+        """y_nodes: the node axis of the WHOLE mesh (Nj_global + 1 entries); a slab context takes
+        its own rows plus one node on either side."""
         x, y = _f64(x_nodes), _f64(y_nodes)
-        if x.shape != (self.ni + 1,) or y.shape != (self.nj + 1,):
+        if x.shape != (self.ni + 1,) or y.shape != (self.nj_global + 1,):
             raise ValueError("node axes must have Ni+1 and Nj+1 entries")
+        if self.nranks > 1:
+            idx = np.clip(np.arange(self.j_offset - 1, self.j_offset + self.nj + 2), 0, self.nj_global)
+            y = np.ascontiguousarray(y[idx])
         check(self.lib.cfd_mesh_from_rect(self._h, dptr(x), dptr(y)))
 
     MESH_PLANES = ("vol", "wr_i", "wn_j", "nix", "niy", "njx", "njy", "s_i", "s_j", "d_i", "d_j", "lmin")
@@ -78,16 +99,34 @@ class Device:
 
     # ---------------------------------------------------------------- fields
     def upload(self, field_id, arr, kind=_lib.KIND_GHOSTED):
-        a = _f64(arr)
+        a = np.asarray(arr)
+        if self.nranks > 1 and a.shape == self.shape(kind, whole=True):
+            from .slab import slab_of
+            a = slab_of(a, self.j_offset, self.nj, kind)     # ghost rows at a cut = the neighbour's rows
+        a = _f64(a)
         if a.shape != self.shape(kind):
             raise ValueError(f"Field shape {a.shape} does not match target {self.shape(kind)}.")
         check(self.lib.cfd_upload_field(self._h, field_id, dptr(a), kind))
 
-    def download(self, field_id, kind=_lib.KIND_GHOSTED, out=None):
+    def download(self, field_id, kind=_lib.KIND_GHOSTED, out=None, whole=False):
+        """whole=True on a j-slab run: every rank receives the assembled global array (collective)."""
+        if whole and self.nranks > 1:
+            from .slab import gather_slabs
+            mine = np.empty(self.shape(kind))
+            check(self.lib.cfd_download_field(self._h, field_id, dptr(mine), kind))
+            full = gather_slabs(mine, kind, self.nj, self.nranks, self.comm.group)
+            if out is None:
+                return full
+            out[...] = full
+            return out
         if out is None:
             out = np.empty(self.shape(kind))
         check(self.lib.cfd_download_field(self._h, field_id, dptr(out), kind))
         return out
+
+    def exchange(self, field_id):
+        """j-slab runs: refresh the ghost rows at the cuts from the neighbour ranks (collective)."""
+        check(self.lib.cfd_exchange_field(self._h, int(field_id)))
 
     def upload_fields(self, fields):
         for name, fid in _lib.FIELD_IDS.items():
@@ -98,7 +137,7 @@ class Device:
         """Refresh the host dict in place (arrays are caller visible, solver.py:333)."""
         for name, fid in _lib.FIELD_IDS.items():
             if name in fields:
-                self.download(fid, out=fields[name])
+                self.download(fid, out=fields[name], whole=True)
         return fields
 
     # ---------------------------------------------------------------- parameters

@@ -266,9 +266,20 @@ def configure_device(dev, config, geometry, nu, turb_on):
                       mg.get("fused", True))
     params = config.get("turbulence", {}).get("params", {})
     dev.set_turbulence_clip(params.get("k_min", 1.0e-10), params.get("omega_min", 1.0e-10))
-    tables = BoundaryTables(config["boundary"], dev.ni, dev.nj, geometry, nu, turb_on)
+    tables = BoundaryTables(config["boundary"], dev.ni, dev.nj_global, geometry, nu, turb_on)
+    if dev.nranks > 1:
+        tables = tables.slab(dev.j_offset, dev.nj)      # geometry and tables are built for the whole mesh
     dev.set_boundary(tables)
     return tables
+
+
+def _distributed_world():
+    """World size of an initialised torch.distributed job (1 otherwise; torch is not imported for it)."""
+    import sys
+    if "torch" not in sys.modules:
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 class StepControl:
@@ -383,7 +394,12 @@ def run_case(config):
     states_dir.mkdir(parents=True, exist_ok=True)
     post_dir.mkdir(parents=True, exist_ok=True)
     log_path = post_dir / f"{case_name}_residual_log.txt"
-    _ensure_single_log_file(post_dir, log_path)
+    writer = True                      # only rank 0 of a j-slab job touches the log files
+    if _distributed_world() > 1:
+        import torch.distributed as dist
+        writer = dist.get_rank() == 0
+    if writer:
+        _ensure_single_log_file(post_dir, log_path)
 
     restart_path = _resolve_restart_state(config, states_dir)
     if restart_path:
@@ -393,12 +409,13 @@ def run_case(config):
         if time is None:
             dt_ref = ctl.dt_max if ctl.dt_max is not None else (ctl.dt or 0.0)
             time = step * dt_ref
-        _truncate_log(post_dir, case_name, step)
+        if writer:
+            _truncate_log(post_dir, case_name, step)
     else:
         fields = initialize_fields(mesh, config["initial"])
         time = 0.0
         step = 0
-        if log_path.exists():
+        if writer and log_path.exists():
             log_path.unlink()
 
     turb_cfg = config.get("turbulence", {})
@@ -410,7 +427,14 @@ def run_case(config):
     elif not turb_on:
         fields["nu_t"][:, :] = 0.0
 
-    dev = Device(count_i, count_j, default_device_ordinal(solver_cfg))
+    # under an initialised torch.distributed job every rank calls run_case with the same CONFIG
+    # and owns one j-slab; rank 0 writes the logs and states, every rank returns the whole fields
+    if _distributed_world() > 1:
+        from .slab import slab_device
+        dev = slab_device(count_i, count_j, default_device_ordinal(solver_cfg))
+    else:
+        dev = Device(count_i, count_j, default_device_ordinal(solver_cfg))
+    root = dev.rank == 0
     try:
         dev.upload_mesh(mesh)
         configure_device(dev, config, BoundaryGeometry.from_nodes(mesh["node"]), nu, turb_on)
@@ -436,7 +460,7 @@ def run_case(config):
                 for key in ("bc", "adv", "mom", "press", "corr", "cont", "turb"):
                     timing[key] = ph[key]
 
-            if cont_res is not None and (residual_log_interval <= 1 or step % residual_log_interval == 0):
+            if root and cont_res is not None and (residual_log_interval <= 1 or step % residual_log_interval == 0):
                 log_residual(post_dir, case_name, step, time, inner_iter, cont_res, mom_u_l2, mom_v_l2)
             if friction_enabled and (friction_log_interval <= 1 or step % friction_log_interval == 0):
                 dev.download_fields(fields)
@@ -452,14 +476,15 @@ def run_case(config):
                     flow_axis=friction_cfg.get("flow_axis", "i"),
                     hydraulic_diameter=friction_cfg.get("hydraulic_diameter"),
                     pressure_gradient=config["physics"].get("pressure_gradient"))
-                log_friction(post_dir, case_name, step, time, friction["cf"], friction["tau_avg"],
-                             bulk_velocity=friction.get("bulk_velocity"), re=friction.get("re"),
-                             cf_dpdx=friction.get("cf_dpdx"))
+                if root:
+                    log_friction(post_dir, case_name, step, time, friction["cf"], friction["tau_avg"],
+                                 bulk_velocity=friction.get("bulk_velocity"), re=friction.get("re"),
+                                 cf_dpdx=friction.get("cf_dpdx"))
 
             elapsed = time_module.perf_counter() - start_wall_time
             if print_interval is None:
                 print_interval = 1
-            if print_interval == 0 or step % int(print_interval) == 0:
+            if root and (print_interval == 0 or step % int(print_interval) == 0):
                 adv_min, diff_min = info["dt_adv"], info["dt_diff"]
                 dt_limit = "fixed"
                 if adv_min is not None and diff_min is not None:
@@ -481,12 +506,13 @@ def run_case(config):
                 if not host_fresh:
                     dev.download_fields(fields)
                     host_fresh = True
-                save_path = save_fields(mesh, fields, states_dir, step, time)
+                if root:
+                    save_path = save_fields(mesh, fields, states_dir, step, time)
+                    print(f"saved {save_path}", flush=True)
                 timing["save"] += time_module.perf_counter() - t0
-                print(f"saved {save_path}", flush=True)
 
             timing["total"] = time_module.perf_counter() - step_start
-            if timing_enabled:
+            if timing_enabled and root:
                 log_timing(post_dir, case_name, step, time, inner_iter, timing)
             time += dt
             step += 1

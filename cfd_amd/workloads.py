@@ -5,11 +5,14 @@ from __future__ import annotations
 import numpy as np
 
 
-def channel_forced_config(n, turbulent=False, max_iter=2, tol=1.0e-8, ratio_j=1.0, steps=1):
-    mesh_params = dict(length_i=1.0, length_j=1.0, count_i=n, count_j=n, ratio_i=1.0, ratio_j=ratio_j)
+def channel_forced_config(n, turbulent=False, max_iter=2, tol=1.0e-8, ratio_j=1.0, steps=1, nj=None, length_j=1.0):
+    """nj / length_j: taller channel of the weak-scaling runs (n x nj cells, same cell size when
+    length_j = nj / n)."""
+    nj = n if nj is None else int(nj)
+    mesh_params = dict(length_i=1.0, length_j=float(length_j), count_i=n, count_j=nj, ratio_i=1.0, ratio_j=ratio_j)
     boundary = {
-        "i_min": {"type": "periodic", "range": (0, n - 1)},
-        "i_max": {"type": "periodic", "range": (0, n - 1)},
+        "i_min": {"type": "periodic", "range": (0, nj - 1)},
+        "i_max": {"type": "periodic", "range": (0, nj - 1)},
         "j_min": {"type": "wall", "range": (0, n - 1)},
         "j_max": {"type": "wall", "range": (0, n - 1)},
         "pressure_reference": {"cell": (0, 0), "value": 0.0},
@@ -39,11 +42,14 @@ def channel_forced_config(n, turbulent=False, max_iter=2, tol=1.0e-8, ratio_j=1.
     return config, mesh_params
 
 
-def perturbed_parabola_rows(n, y_nodes, seed=1234, u_max=1.0):
+def perturbed_parabola_rows(n, y_nodes, seed=1234, u_max=1.0, j_offset=0, nj_local=None):
     """u = U (1 - (2y/H - 1)^2) + 1e-3 N(0,1) on the (Ni, Nj) interior (rect mesh: cell-centre
-    y is the mid-point of the node rows)."""
+    y is the mid-point of the node rows).  j_offset / nj_local: only the rows of one j-slab, with
+    the noise stream seeded per slab (seed + j_offset) so that no rank draws the whole field."""
     y_nodes = np.asarray(y_nodes)
     yc = 0.5 * (y_nodes[1:] + y_nodes[:-1])
     h = float(y_nodes[-1] - y_nodes[0])
-    rng = np.random.default_rng(seed)
-    return (u_max * (1.0 - (2.0 * yc / h - 1.0) ** 2))[None, :] + 1.0e-3 * rng.standard_normal((n, n))
+    nj_local = len(yc) - j_offset if nj_local is None else int(nj_local)
+    yc = yc[j_offset:j_offset + nj_local]
+    rng = np.random.default_rng(seed + j_offset)
+    return (u_max * (1.0 - (2.0 * yc / h - 1.0) ** 2))[None, :] + 1.0e-3 * rng.standard_normal((n, nj_local))

@@ -84,6 +84,36 @@ int cfd_version(void);
 size_t cfd_workspace_bytes(int ni, int nj);
 int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes);
 int cfd_destroy(cfd_ctx *ctx);
+
+/* ---- j-slab decomposition (no counterpart in the single-process
+ * reference, whose run_case owns the whole mesh, solver.py:1367-1451) ----------------
+ * One context per rank holds rows [j_offset, j_offset + nj_local) of a global (Ni, nj_global)
+ * mesh; nj_local is the same on every rank and even.  Ghost rows at a cut carry the
+ * neighbour's interior rows; physical j boundaries exist only on the first / last rank.
+ * The multigrid hierarchy is slab-distributed on its fine levels and replicated
+ * ("agglomerated") below.  Periodicity along j is not supported across slabs.
+ * All arrays passed to the other entry points are the slab-local slices; side tables of
+ * i_min / i_max have nj_local entries.  cfd_mesh_from_rect takes y_nodes with nj_local + 3
+ * entries starting one node below the slab; cfd_mesh_from_nodes is single-rank only.
+ * Communication goes through three callbacks that the host implements on the context's
+ * stream (torch.distributed over RCCL in cfd_amd/slab.py); each returns 0 on success.   */
+/* exchange `depth` rows at each cut of `nplanes` planes of pitch `pitch` (doubles) and
+ * nj_local interior rows: plane row r holds j = r - 2.  My rows [nj_local-depth, nj_local) go to
+ * rows [-depth, 0) of rank+1, my rows [0, depth) to rows [nj_local, nj_local+depth) of rank-1.  */
+typedef int (*cfd_halo_fn)(void *user, int nplanes, double *const *planes, int pitch, int nj_local, int depth);
+/* in-place all-reduce of n device doubles; op 0 = sum, 1 = min                                  */
+typedef int (*cfd_allreduce_fn)(void *user, double *dev, int n, int op);
+/* dst[rank * elems .. (rank+1) * elems) = src of that rank, for all ranks (device pointers)     */
+typedef int (*cfd_allgather_fn)(void *user, const double *src, double *dst, size_t elems);
+size_t cfd_workspace_bytes_slab(int ni, int nj_local, int nranks);
+int cfd_create_slab(cfd_ctx **out, int ni, int nj_local, int device, void *workspace, size_t workspace_bytes,
+                    int rank, int nranks);
+int cfd_set_comm(cfd_ctx *ctx, cfd_halo_fn halo, cfd_allreduce_fn allreduce, cfd_allgather_fn allgather, void *user);
+/* refresh the cut ghost rows of a field plane (after cfd_upload_field on every rank)            */
+int cfd_exchange_field(cfd_ctx *ctx, int field_id);
+/* number of multigrid levels and index of the first replicated one (0 on a single rank)         */
+int cfd_level_info(cfd_ctx *ctx, int *n_levels, int *first_replicated);
+
 int cfd_set_stream(cfd_ctx *ctx, void *hip_stream);
 int cfd_synchronize(cfd_ctx *ctx);
 int cfd_pitch(cfd_ctx *ctx);                       /* row pitch in doubles          */

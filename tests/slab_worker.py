@@ -1,0 +1,114 @@
+"""One rank of a j-slab run (started by tests/test_gpu_slab.py, once per rank).
+
+    RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment
+    python tests/slab_worker.py <case> <out_dir> <backend>
+
+Every rank shares GPU 0 (the test box has one GPU), so the transport is gloo with host
+staging; on a multi-GPU node the same code runs with backend nccl and one GPU per rank.
+Rank 0 writes <out_dir>/result.npz.
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def build_case(name, work):
+    from oracle import cases
+    from cfd_amd import mesh as hip_mesh
+    table = {
+        "channel_komega_48x64": (lambda: cases.channel_forced(n=64, steps=3, turbulent=True, ratio_j=1.02), cases.perturbed_parabola, {"count_i": 48}),
+        "channel_lam_64x128": (lambda: cases.channel_forced(n=64, steps=2, ratio_j=1.0), cases.perturbed_parabola, {"count_j": 128}),
+        "inlet_outlet_40x32": (lambda: cases.inlet_outlet_channel(ni=40, nj=32, steps=4), None, {}),
+        "couette_piso_24x32": (lambda: cases.couette_piso(ni=24, nj=32, steps=4), cases.perturbed_rest, {}),
+        "half_cylinder_komega_24x32": (lambda: cases.half_cylinder(nr=24, nt=32, steps=3, turbulent=True), None, {}),
+    }
+    builder, fixup, mp_over = table[name]
+    cfg, mp, kind = builder()
+    if mp_over:
+        # non-square variants of the square channel builder: patch the counts and the BC ranges
+        mp.update(mp_over)
+        ni, nj = mp["count_i"], mp["count_j"]
+        for side, n in (("i_min", nj), ("i_max", nj), ("j_min", ni), ("j_max", ni)):
+            cfg["boundary"][side]["range"] = (0, n - 1)
+    gen = hip_mesh.generate_rect_mesh if kind == "rect" else hip_mesh.generate_annulus_mesh
+    cfg["mesh"] = {"generator": gen, "params": mp, "path": work / "mesh" / "mesh.npz"}
+    cfg["paths"] = {"case_dir": work, "mesh_dir": work / "mesh", "states_dir": work / "states",
+                    "post_dir": work / "postproc"}
+    mesh = hip_mesh.make_mesh(cfg["mesh"])
+    if fixup is not None:
+        fixup(cfg, mesh)
+    cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+    if os.environ.get("SLAB_UNFUSED"):
+        cfg["solver"]["multigrid"] = {"fused": False}
+    return cfg
+
+
+def mesh_from_rect_check(out_dir, rank, world):
+    """Slab metrics computed on the device from the node axes (one halo node per side, cut face rows
+    from the neighbour) against the slices of the host mesh contract."""
+    import torch.distributed as dist
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd.slab import slab_device, slab_mesh
+    mp = dict(length_i=2.0, length_j=1.0, count_i=40, count_j=48, ratio_i=1.03, ratio_j=1.05)
+    x, y = hip_mesh.rect_node_axes(**mp)
+    host = hip_mesh.precompute_from_nodes(hip_mesh.generate_rect_nodes(**mp))
+    dev = slab_device(mp["count_i"], mp["count_j"], 0)
+    dev.mesh_from_rect(x, y)
+    sl = slab_mesh(host, dev.j_offset, dev.nj)
+    want = {"vol": sl["cell_volume"], "wr_i": sl["w_right_i"], "wn_j": sl["w_north_j"],
+            "nix": sl["face_normal_i"][..., 0], "niy": sl["face_normal_i"][..., 1],
+            "njx": sl["face_normal_j"][..., 0], "njy": sl["face_normal_j"][..., 1],
+            "s_i": np.hypot(sl["face_normal_i"][..., 0], sl["face_normal_i"][..., 1]),
+            "s_j": np.hypot(sl["face_normal_j"][..., 0], sl["face_normal_j"][..., 1]),
+            "d_i": sl["diff_d_i"], "d_j": sl["diff_d_j"],
+            "lmin": np.minimum(sl["cell_spacing_i"], sl["cell_spacing_j"])}
+    worst = 0.0
+    for name, ref in want.items():
+        got = dev.download_mesh_plane(name)
+        scale = max(1.0, float(np.abs(ref).max()))
+        worst = max(worst, float(np.abs(got - ref).max() / scale))
+    dev.close()
+    allw = [None] * world
+    if world > 1:
+        dist.all_gather_object(allw, worst)
+    else:
+        allw = [worst]
+    if rank == 0:
+        np.savez(out_dir / "result.npz", worst=np.array(allw))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
+    name, out_dir, backend = sys.argv[1], Path(sys.argv[2]), sys.argv[3]
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    work = out_dir / f"rank{rank}"
+    work.mkdir(parents=True, exist_ok=True)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if name == "mesh_from_rect":
+        return mesh_from_rect_check(out_dir, rank, world)
+    from cfd_amd import solver as hip_solver
+    cfg = build_case(name, work)
+    cfg["solver"]["device"] = 0
+    fields, step, time = hip_solver.run_case(cfg)
+    if rank == 0:
+        log = np.loadtxt(work / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+        np.savez(out_dir / "result.npz", step=step, time=time, log=log, **{f"field_{k}": v for k, v in fields.items()})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""j-slab decomposition on the GPU: N ranks, each with its own libcfd_hip
+context holding one slab, must reproduce the single-rank run.  The box has one GPU, so the
+ranks share it and exchange through gloo with host staging; the halo / all-reduce /
+all-gather logic and every kernel's cut handling are the ones the RCCL path uses."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import mask_corners
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(case, world, out_dir):
+    out_dir.mkdir(parents=True, exist_ok=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for rank in range(world):
+        e = dict(env, RANK=str(rank), LOCAL_RANK="0")
+        log = open(out_dir / f"rank{rank}.log", "w")
+        procs.append((subprocess.Popen([sys.executable, "-u", str(ROOT / "tests" / "slab_worker.py"), case, str(out_dir), "gloo"],
+                                       env=e, stdout=log, stderr=subprocess.STDOUT, cwd=str(ROOT)), log))
+    failed = []
+    for rank, (p, log) in enumerate(procs):
+        try:
+            rc = p.wait(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = -9
+        log.close()
+        if rc != 0:
+            failed.append((rank, rc))
+    if failed:
+        for _, (p, _) in enumerate(procs):
+            if p.poll() is None:
+                p.kill()
+        tail = "\n".join(f"--- rank {r} (exit {rc})\n" + (out_dir / f"rank{r}.log").read_text()[-3000:] for r, rc in failed)
+        raise AssertionError(f"slab run failed: {tail}")
+    return np.load(out_dir / "result.npz")
+
+
+@pytest.mark.parametrize("case,world", [
+    ("channel_komega_48x64", 2), ("channel_komega_48x64", 4), ("channel_lam_64x128", 2),
+    ("inlet_outlet_40x32", 2), ("couette_piso_24x32", 2), ("half_cylinder_komega_24x32", 2),
+])
+def test_slab_run_matches_single_rank(case, world, tmp_path):
+    one = _run(case, 1, tmp_path / "w1")
+    many = _run(case, world, tmp_path / f"w{world}")
+    assert int(one["step"]) == int(many["step"])
+    assert abs(float(one["time"]) - float(many["time"])) <= 1e-12 * max(1.0, abs(float(one["time"])))
+    unorm = max(1.0, np.linalg.norm(one["field_u"].ravel()))
+    for key in [k for k in one.files if k.startswith("field_") and k != "field_p_corr"]:
+        a, b = mask_corners(one[key]), mask_corners(many[key])
+        err, den = np.linalg.norm((a - b).ravel()), np.linalg.norm(a.ravel())
+        assert err <= 1e-10 * den + 1e-12 * unorm, (key, err, den)
+    la, lb = one["log"], many["log"]
+    assert la.shape == lb.shape
+    assert np.array_equal(la[:, 0], lb[:, 0]) and np.array_equal(la[:, 2], lb[:, 2])     # steps, inner iterations
+    assert np.all(np.abs(la[:, 3] - lb[:, 3]) <= 1e-6 * np.abs(la[:, 3]) + 1e-13)        # continuity history
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_slab_mesh_from_rect(world, tmp_path):
+    """cfd_mesh_from_rect on slabs (halo node below, cut face row from the rank above) reproduces
+    the slices of the host mesh contract on every rank."""
+    res = _run("mesh_from_rect", world, tmp_path / f"m{world}")
+    assert res["worst"].shape == (world,)
+    assert np.all(res["worst"] <= 1e-12), res["worst"]

@@ -1,0 +1,174 @@
+"""CPU tests of the j-slab layer: partition, table slicing, and the three
+collectives of cfd_amd.slab.SlabComm run by two gloo ranks on host tensors (the same code that
+moves device views over RCCL; here the 'workspace' is a host tensor)."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def test_partition():
+    from cfd_amd.slab import partition
+    assert partition(64, 1, 0) == (0, 64)
+    assert partition(64, 4, 3) == (48, 16)
+    assert partition(7, 1, 0) == (0, 7)            # single rank: no constraint
+    with pytest.raises(ValueError):
+        partition(66, 4, 0)                         # not divisible
+    with pytest.raises(ValueError):
+        partition(12, 4, 0)                         # odd slabs
+    with pytest.raises(ValueError):
+        partition(64, 4, 4)
+
+
+def test_boundary_tables_slab():
+    """Slab tables = the global tables restricted to the slab rows; k/omega ops re-based."""
+    from cfd_amd import _lib as L
+    from cfd_amd.bc import BoundaryGeometry, BoundaryTables
+    from cfd_amd.mesh import rect_node_axes
+    ni, nj = 6, 16
+    x, y = rect_node_axes(length_i=2.0, length_j=1.0, count_i=ni, count_j=nj, ratio_i=1.0, ratio_j=1.1)
+    geo = BoundaryGeometry.from_rect_axes(x, y)
+    bc = {"i_min": [{"type": "inlet", "range": (0, 9), "velocity": (1.0, 0.0), "k": 1e-3, "omega": 5.0},
+                    {"type": "wall", "range": (10, 15)}],
+          "i_max": {"type": "outlet", "range": (0, 15), "pressure": 0.0},
+          "j_min": {"type": "wall", "range": (0, 5)}, "j_max": {"type": "symmetry", "range": (0, 5)}}
+    full = BoundaryTables(bc, ni, nj, geo, 1e-3, True)
+    parts = [full.slab(j0, 4) for j0 in (0, 4, 8, 12)]
+    for side in (0, 1):
+        for key in full.flow[side]:
+            assert np.array_equal(np.concatenate([p.flow[side][key] for p in parts]), full.flow[side][key])
+        assert np.array_equal(np.concatenate([p.p_masks[side] for p in parts]), full.p_masks[side])
+    # replay the k/omega programs: ops of all slabs together touch exactly what the global program touches
+    def touched(tab, j0, njl):
+        out = {}
+        for (op, field, side, lo, hi, off, a) in tab.turb_ops:
+            if op in (L.TOP_WRAP_I, L.TOP_WRAP_J):
+                continue
+            for q in range(lo, hi + 1):
+                idx = q + j0 if side < 2 else q
+                out.setdefault((op, field, side, idx), []).append((a, tab.turb_values[off + q - lo]))
+        return out
+    want = touched(full, 0, nj)
+    got = {}
+    for p, j0 in zip(parts, (0, 4, 8, 12)):
+        for k, v in touched(p, j0, 4).items():
+            got.setdefault(k, []).extend(v)
+    assert got == want
+    assert all(o[2] != 2 for o in parts[1].turb_ops + parts[2].turb_ops + parts[3].turb_ops)   # j_min only on the first
+    assert all(o[2] != 3 for o in parts[0].turb_ops + parts[1].turb_ops + parts[2].turb_ops)   # j_max only on the last
+    with pytest.raises(NotImplementedError):
+        BoundaryTables({"j_min": {"type": "periodic", "range": (0, 5)}, "j_max": {"type": "periodic", "range": (0, 5)},
+                        "i_min": {"type": "wall", "range": (0, 15)}, "i_max": {"type": "wall", "range": (0, 15)}},
+                       ni, nj, geo, 1e-3, False).slab(0, 8)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _comm_worker(rank, world, port, out_q):
+    try:
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cfd_amd import _lib as L
+        from cfd_amd.slab import SlabComm, gather_slabs, partition, slab_of
+        pitch, njl, nplanes = 32, 6, 3
+        rows = njl + 4
+        ws = torch.zeros((nplanes * rows * pitch + 64) * 8, dtype=torch.uint8)
+        comm = SlabComm(ws, rank, world)
+        f = comm.f64
+        planes = [comm.base + 8 * q * rows * pitch for q in range(nplanes)]
+
+        def fill():
+            for q in range(nplanes):
+                v = f[q * rows * pitch:(q + 1) * rows * pitch].view(rows, pitch)
+                v.fill_(-1.0)
+                for r in range(2, 2 + njl):          # interior row j = r - 2 -> code rank, plane, global row
+                    v[r] = 1000.0 * rank + 100.0 * q + (rank * njl + r - 2) + 0.001 * torch.arange(pitch, dtype=torch.float64)
+        for depth in (1, 2):
+            fill()
+            comm.halo(planes, pitch, njl, depth)
+            for q in range(nplanes):
+                v = f[q * rows * pitch:(q + 1) * rows * pitch].view(rows, pitch)
+                col = 0.001 * torch.arange(pitch, dtype=torch.float64)
+                for d in range(1, depth + 1):
+                    lo, hi = v[2 - d], v[2 + njl + d - 1]
+                    if rank > 0:
+                        assert torch.equal(lo, 1000.0 * (rank - 1) + 100.0 * q + (rank * njl - d) + col), (depth, d)
+                    else:
+                        assert torch.all(lo == -1.0)
+                    if rank < world - 1:
+                        assert torch.equal(hi, 1000.0 * (rank + 1) + 100.0 * q + ((rank + 1) * njl + d - 1) + col)
+                    else:
+                        assert torch.all(hi == -1.0)
+                if depth == 1:
+                    assert torch.all(v[0] == -1.0) and torch.all(v[rows - 1] == -1.0)     # outer halo rows untouched
+        # all-reduce sum / min on scalars at the end of the workspace
+        s_off = nplanes * rows * pitch
+        f[s_off:s_off + 3] = torch.tensor([1.0 + rank, 10.0 * (rank + 1), -float(rank)], dtype=torch.float64)
+        comm.all_reduce(comm.base + 8 * s_off, 3, 0)
+        assert f[s_off:s_off + 3].tolist() == [sum(1.0 + r for r in range(world)), sum(10.0 * (r + 1) for r in range(world)),
+                                               -float(sum(range(world)))]
+        f[s_off:s_off + 2] = torch.tensor([5.0 - rank, 2.0 + rank], dtype=torch.float64)
+        comm.all_reduce(comm.base + 8 * s_off, 2, 1)
+        assert f[s_off:s_off + 2].tolist() == [5.0 - (world - 1), 2.0]
+        # all-gather of slab rows into a replicated plane (plane 2 used as destination)
+        fill()
+        src = planes[0] + 8 * 2 * pitch
+        dst = planes[2] + 8 * 2 * pitch
+        n_each = 2 * pitch                              # 2 rows per rank -> 2 * world rows <= njl
+        comm.all_gather(src, dst, n_each)
+        g = f[2 * rows * pitch:3 * rows * pitch].view(rows, pitch)
+        for r in range(world):
+            for k in range(2):
+                assert g[2 + 2 * r + k, 0].item() == 1000.0 * r + (r * njl + k)
+        assert (comm.n_halo, comm.n_reduce, comm.n_gather) == (2, 2, 1)
+        # out-of-workspace pointers are refused, and a failing callback reports instead of raising through C
+        assert comm._reduce_cb(None, comm.base - 8, 1, 0) == 1 and isinstance(comm.error, ValueError)
+        L.LAST_CALLBACK_ERROR = None
+        # host slicing / gathering round trip for every array kind
+        rng = np.random.default_rng(5)
+        ni, njg = 5, njl * world
+        j0, nl = partition(njg, world, rank) if njl % 2 == 0 else (rank * njl, njl)
+        for kind, shape in ((L.KIND_GHOSTED, (ni + 2, njg + 2)), (L.KIND_CELL, (ni, njg)),
+                            (L.KIND_FACE_I, (ni + 1, njg)), (L.KIND_FACE_J, (ni, njg + 1))):
+            whole = rng.standard_normal(shape)
+            mine = slab_of(whole, j0, nl, kind)
+            back = gather_slabs(mine, kind, nl, world)
+            assert np.array_equal(back, whole), kind
+        dist.barrier()
+        dist.destroy_process_group()
+        out_q.put((rank, "ok"))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        out_q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_collectives_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    for _ in procs:
+        results.append(q.get(timeout=120))
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    bad = [r for r in results if r[1] != "ok"]
+    assert not bad, "\n".join(f"rank {r}: {msg}" for r, msg in bad)
