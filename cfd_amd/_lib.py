@@ -30,7 +30,7 @@ class TurbOp(C.Structure):
 
 class SolveStats(C.Structure):
     _fields_ = [("mom_iters", C.c_int32), ("p_iters", C.c_int32), ("k_iters", C.c_int32),
-                ("p_solver", C.c_int32), ("mom_relres", C.c_double * 2), ("p_relres", C.c_double),
+                ("p_solver", C.c_int32), ("mom_solver", C.c_int32), ("k_solver", C.c_int32), ("mom_relres", C.c_double * 2), ("p_relres", C.c_double),
                 ("k_relres", C.c_double * 2)]
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "cfd_set_physics": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]),
     "cfd_set_solver": (C.c_int, [_vp, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]),
     "cfd_set_multigrid": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
+    "cfd_set_transport_solver": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int]),
     "cfd_set_turbulence_clip": (C.c_int, [_vp, C.c_double, C.c_double]),
     "cfd_set_flow_bc": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip] + [_dp] * 8),
     "cfd_set_periodicity": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),

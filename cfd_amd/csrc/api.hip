@@ -517,6 +517,14 @@ int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int c
     return CFD_OK;
 }
 
+int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double rho_max, int max_iters) {
+    CTX(ctx);
+    if (!(rho_max > 0.0 && rho_max < 1.0) || max_iters < 1) { set_error("cfd_set_transport_solver: bad parameters"); return CFD_E_ARG; }
+    c->warm_start = warm_start ? 1 : 0; c->use_chebyshev = chebyshev ? 1 : 0;
+    c->cheb_rho_max = rho_max; c->cheb_max_iters = max_iters;
+    return CFD_OK;
+}
+
 int cfd_set_turbulence_clip(cfd_ctx *ctx, double k_min, double omega_min) {
     CTX(ctx);
     c->k_clip = k_min; c->omega_clip = omega_min;
@@ -669,6 +677,7 @@ static int do_predictor(Ctx *c, double dt, double res[3]) {
         CFD_TRY(momentum_like_solve(c, op, b, x, c->warm_start ? x0 : nullptr, 2, c->mom_tol, c->mom_maxiter, &it,
                                     c->stats.mom_relres, rms));
         c->stats.mom_iters = it;
+        c->stats.mom_solver = c->stats_last_solver;
         res[1] = rms[0];
         res[2] = rms[1];
     }
@@ -780,6 +789,7 @@ int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
     CFD_TRY(momentum_like_solve(c, op, b, x, c->warm_start ? x0 : nullptr, 2, c->turb_tol, c->turb_maxiter, &it,
                                 c->stats.k_relres, nullptr));
     c->stats.k_iters = it;
+    c->stats.k_solver = c->stats_last_solver;
     CFD_TRY(launch_clip(c, c->k, c->k_clip));
     CFD_TRY(launch_clip(c, c->omega, c->omega_clip));
     CFD_TRY(launch_turb_bc(c));
@@ -861,6 +871,7 @@ int cfd_momentum_solve(cfd_ctx *ctx, double res[2]) {
     CFD_TRY(momentum_like_solve(c, op, b, x, c->warm_start ? x0 : nullptr, 2, c->mom_tol, c->mom_maxiter, &it,
                                 c->stats.mom_relres, res));
     c->stats.mom_iters = it;
+    c->stats.mom_solver = c->stats_last_solver;
     // the fine-grained API works in place on the current planes (like the reference): copy the interior
     for (int q = 0; q < 2; ++q) {
         double *dst = q == 0 ? c->U() : c->V();

@@ -166,6 +166,10 @@ struct Ctx {
     int mg_pre = 2, mg_post = 2, mg_coarse_sweeps = 40, mg_min = 4;
     double mg_omega = 0.8;
     int warm_start = 1;          // Krylov initial guess = previous field (reference: zero)
+    int use_chebyshev = 1;       // Chebyshev semi-iteration for time-step dominated transport systems
+    double cheb_rho_max = 0.95;  // ... i.e. Jacobi row-sum bound below this
+    int cheb_max_iters = 80;     // ... and predicted iteration count below this; else BiCGStab
+    int stats_last_solver = 0;   // 1 = the last transport solve was Chebyshev
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
     double k_clip = 1e-10, omega_clip = 1e-10;
     double dt_ap = -1.0;          // dt the a_P plane was built with

@@ -155,6 +155,10 @@ class Device:
         check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(omega), int(coarse_sweeps),
                                          int(bool(fused))))
 
+    def set_transport_solver(self, warm_start=True, chebyshev=True, rho_max=0.95, max_iters=80):
+        check(self.lib.cfd_set_transport_solver(self._h, int(bool(warm_start)), int(bool(chebyshev)), float(rho_max),
+                                                int(max_iters)))
+
     def set_turbulence_clip(self, k_min, omega_min):
         check(self.lib.cfd_set_turbulence_clip(self._h, float(k_min), float(omega_min)))
 
@@ -209,6 +213,8 @@ class Device:
         check(self.lib.cfd_get_stats(self._h, C.byref(s)))
         return {"mom_iters": s.mom_iters, "p_iters": s.p_iters, "k_iters": s.k_iters,
                 "p_solver": "mg-pcg" if s.p_solver == 0 else "mg-bicgstab",
+                "mom_solver": "chebyshev" if s.mom_solver == 1 else "bicgstab",
+                "k_solver": "chebyshev" if s.k_solver == 1 else "bicgstab",
                 "mom_relres": tuple(s.mom_relres), "p_relres": s.p_relres, "k_relres": tuple(s.k_relres)}
 
     def bulk_velocity(self, field_id=_lib.F_U):

@@ -13,7 +13,12 @@ Extensions over the reference (all optional, defaults reproduce the reference):
       (cached hierarchy keyed on shape only, solver.py:821-833).  False =
       the reference's no-pyamg branch (fresh matrix every solve, solver.py:834-845).
   solver.turbulence_solver.{tol, maxiter}  (reference: hard-coded 1e-8 / 200).
-  solver.multigrid.{nu_pre, nu_post, omega, coarse_sweeps}.
+  solver.multigrid.{nu_pre, nu_post, omega, coarse_sweeps, fused}.
+  solver.transport.{warm_start, chebyshev, rho_max, max_iters}  momentum / k-omega solver policy
+      (Jacobi-Chebyshev for time-step dominated systems, Jacobi-BiCGStab otherwise; the
+      reference's stopping test |r| <= tol |b| either way).
+  torch.distributed initialised with world > 1: every rank calls run_case with the same CONFIG
+      and owns one j-slab (cfd_amd/slab.py); rank 0 writes logs and states.
   solver.device  HIP device ordinal (default 0 or LOCAL_RANK).
   time.dt without time.cfl: true fixed-dt mode (the reference crashes there).
 """
@@ -264,6 +269,9 @@ def configure_device(dev, config, geometry, nu, turb_on):
                    pressure_cfg.get("freeze_operator", True))
     dev.set_multigrid(mg.get("nu_pre", 2), mg.get("nu_post", 2), mg.get("omega", 0.8), mg.get("coarse_sweeps", 40),
                       mg.get("fused", True))
+    tr = solver_cfg.get("transport", {})
+    dev.set_transport_solver(tr.get("warm_start", True), tr.get("chebyshev", True), tr.get("rho_max", 0.95),
+                             tr.get("max_iters", 80))
     params = config.get("turbulence", {}).get("params", {})
     dev.set_turbulence_clip(params.get("k_min", 1.0e-10), params.get("omega_min", 1.0e-10))
     tables = BoundaryTables(config["boundary"], dev.ni, dev.nj_global, geometry, nu, turb_on)

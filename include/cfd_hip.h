@@ -64,10 +64,12 @@ typedef struct cfd_turb_op {
 } cfd_turb_op;
 
 typedef struct cfd_solve_stats {
-    int32_t mom_iters;       /* BiCGStab iterations of the (u, v) predictor         */
+    int32_t mom_iters;       /* iterations of the (u, v) predictor solve            */
     int32_t p_iters;         /* Krylov iterations of the last pressure solve        */
-    int32_t k_iters;         /* BiCGStab iterations of the (k, omega) transport     */
+    int32_t k_iters;         /* iterations of the (k, omega) transport solve        */
     int32_t p_solver;        /* 0 = MG-PCG, 1 = MG-BiCGStab (asymmetric seam)       */
+    int32_t mom_solver;      /* 0 = Jacobi-BiCGStab, 1 = Jacobi-Chebyshev           */
+    int32_t k_solver;        /* same for (k, omega)                                 */
     double mom_relres[2];    /* final |r|/|b| of u and v                            */
     double p_relres;         /* final |r|/|b| of the pressure correction            */
     double k_relres[2];
@@ -161,6 +163,14 @@ int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, 
 /* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps; fused = 1 uses
  * the temporally blocked (two sweeps per pass) marching kernels when nu_pre = nu_post = 2  */
 int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused);
+/* Transport (momentum, k-omega) solver policy; replaces the reference's spilu + scipy bicgstab
+ * with x0 = 0 (solver.py:785-818), same stopping test |b - A x| <= tol |b|.
+ *   warm_start : start from the previous field instead of zero;
+ *   chebyshev  : Jacobi-Chebyshev semi-iteration (no inner products) whenever the Jacobi row-sum
+ *                bound rho = max sum_n c_n / D is <= rho_max and the Chebyshev bound predicts
+ *                <= max_iters iterations (time-step dominated systems); Jacobi-BiCGStab otherwise
+ *                and whenever warm_start is off.                                              */
+int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double rho_max, int max_iters);
 /* turbulence clip after the k/omega solve (solver.py:1147-1151)                       */
 int cfd_set_turbulence_clip(cfd_ctx *ctx, double k_min, double omega_min);
 

@@ -394,3 +394,64 @@ def test_properties_at_scale(n):
     u2 = dev.download(L.F_U)
     assert np.abs(u2[1:-1, 1:-1] - f["u"][1:-1, 1:-1]).max() <= 1e-5 * amp   # wall-cell truncation 2 amp nu dt
     dev.close()
+
+
+@pytest.mark.parametrize("turbulent", [False, True])
+def test_chebyshev_transport_matches_bicgstab(turbulent, tmp_path):
+    """The Jacobi-Chebyshev semi-iteration (time-step dominated systems) and Jacobi-BiCGStab solve
+    the same systems to the same tolerance: same fields after 3 steps, Chebyshev actually chosen,
+    and it falls back to BiCGStab when the row-sum bound is too close to one."""
+    from cfd_amd import _lib as L
+    from cfd_amd.bc import BoundaryGeometry
+    from cfd_amd.device import Device
+    from cfd_amd.mesh import rect_node_axes
+    from cfd_amd.solver import StepControl, advance_one_step, configure_device
+    from cfd_amd.workloads import channel_forced_config, perturbed_parabola_rows
+    n = 96
+    results = {}
+    for mode in ("chebyshev", "bicgstab", "forced_fallback"):
+        cfg, mp = channel_forced_config(n, turbulent, 2, 1e-12, ratio_j=1.02)
+        cfg["solver"]["transport"] = {"chebyshev": mode != "bicgstab",
+                                      "rho_max": 1e-6 if mode == "forced_fallback" else 0.95}
+        x, y = rect_node_axes(**mp)
+        dev = Device(n, n, 0)
+        dev.mesh_from_rect(x, y)
+        ctl = StepControl(cfg)
+        configure_device(dev, cfg, BoundaryGeometry.from_rect_axes(x, y), cfg["physics"]["nu"], ctl.turb_on)
+        f = np.zeros((n + 2, n + 2))
+        f[1:-1, 1:-1] = perturbed_parabola_rows(n, y, seed=7)
+        dev.upload(L.F_U, f)
+        f[:] = 0.0
+        for fid in (L.F_V, L.F_P, L.F_NUT):
+            dev.upload(fid, f)
+        if turbulent:
+            f[1:-1, 1:-1] = 1e-4
+            dev.upload(L.F_K, f)
+            f[1:-1, 1:-1] = 10.0
+            dev.upload(L.F_OMEGA, f)
+        used = []
+        for step in range(3):
+            info = advance_one_step(dev, ctl, step)
+            st = dev.stats()
+            used.append((st["mom_solver"], st["k_solver"], st["mom_iters"]))
+            assert max(st["mom_relres"]) <= 1e-12 and (not turbulent or max(st["k_relres"]) <= 1e-12)
+        results[mode] = ({k: dev.download(fid) for k, fid in L.FIELD_IDS.items() if k != "p_corr"}, used, info)
+        dev.close()
+    # laminar: every step is time-step dominated.  k-omega: the eddy viscosity that develops on this
+    # perturbed start pushes the row-sum bound past rho_max after the first step, and the policy
+    # must then hand over to BiCGStab by itself.
+    msg = (results["chebyshev"][1], results["bicgstab"][1])
+    if turbulent:
+        assert results["chebyshev"][1][0][:2] == ("chebyshev", "chebyshev"), msg
+    else:
+        assert all(u[0] == "chebyshev" for u in results["chebyshev"][1]), msg
+    assert all(u[0] == "bicgstab" for u in results["bicgstab"][1] + results["forced_fallback"][1])
+    ref = results["bicgstab"][0]
+    for mode in ("chebyshev", "forced_fallback"):
+        for key, a in results[mode][0].items():
+            if not turbulent and key in ("k", "omega"):
+                continue
+            den = max(np.linalg.norm(mask_corners(ref[key]).ravel()), 1e-300)
+            err = np.linalg.norm((mask_corners(a) - mask_corners(ref[key])).ravel())
+            # p integrates the O(tol) velocity differences with a 1/dt weight
+            assert err <= (1e-6 if key == "p" else 1e-9) * den + 1e-12, (mode, key, err, den)
