@@ -173,9 +173,9 @@ def main():
         kernel_names = {0: "pressure SpMV (k_cg_q)",
                         1: "MG pre-smoother, finest level: 2 fused Jacobi sweeps + residual + restrict (k_mg_down<true>)",
                         2: "momentum RHS (k_momentum_rhs)", 3: "batched momentum operator (k_bi_apply<2>)",
-                        8: "momentum Chebyshev pass, u and v together: residual + update (k_cheb<2>)",
+                        8: "momentum Chebyshev, two fused iterations of u and v per launch (k_cheb2<2>)",
                         7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
-        bytes_per_cell = {0: 40, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 88}[args.probe]
+        bytes_per_cell = {0: 40, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]
         achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,

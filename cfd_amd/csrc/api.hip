@@ -136,7 +136,7 @@ static std::vector<Geo> level_geometry_slab(int ni, int nj_loc, int nranks, int 
 
 static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 constexpr int N_FINE_PLANES = 12 + 6 + 3 + 4 + 3 + 3 + 2 + 2 + 16 + 3;
-constexpr size_t MISC_BYTES = (size_t)4 * MAX_PARTIALS * sizeof(double) + 4096;
+constexpr size_t MISC_BYTES = (size_t)8 * MAX_PARTIALS * sizeof(double) + 4096;
 
 static size_t workspace_bytes_impl(int ni, int nj, int nranks, size_t bc_bytes) {
     int l_agg = 0;
@@ -270,7 +270,7 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
             L.s0 = (double *)cv.take(sb); L.s1 = (double *)cv.take(sb); L.s2 = (double *)cv.take(sb);
         }
     }
-    c->partials = (double *)cv.take((size_t)4 * MAX_PARTIALS * sizeof(double));
+    c->partials = (double *)cv.take((size_t)8 * MAX_PARTIALS * sizeof(double));
     c->scal = (double *)cv.take(2048);
     c->bc_buf = (char *)cv.take(bc_bytes_for(ni, nj));
     if (!c->bc_buf) { set_error("internal: workspace carve overflow"); return CFD_E_ARG; }

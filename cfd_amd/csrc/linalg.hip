@@ -470,208 +470,6 @@ static int bicgstab_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *
     return CFD_OK;
 }
 
-// ------------------------------------------------------------------ Chebyshev (time-step dominated systems)
-// The transport matrices are  A = V/dt + sum a_f  on the diagonal and -a_f off it.  With
-// Jacobi scaling the spectrum of D^-1 A lies in [1 - rho, 1 + rho], rho = max_P sum_n c_n / D_P
-// (row-sum bound, rigorous).  When the step is CFL-limited rho is well below one (2/3 at
-// cfl_diff = 0.5 on a uniform mesh) and the Chebyshev semi-iteration on that interval converges
-// like CG *without any inner product*: one fused pass per iteration
-//     r_k = b - A x_k ; d_k = c1 (x_k - x_{k-1}) + c2 r_k / D ; x_{k+1} = x_k + d_k
-// (88 B/cell for two right-hand sides), |r_k|^2 falls out as a by-product and the host looks at
-// it only around the iteration the Chebyshev bound predicts.  The stopping test is the
-// reference's, |b - A x| <= tol |b| on the returned iterate.  Systems with rho close to one
-// (large dt) go to BiCGStab below.
-__global__ void k_rowsum_bound(OpDev op, Tiling T, double *partials) {
-    const Geo g = op.g;
-    double m = 0.0;
-    TILE_LOOP(g, T) {
-        const size_t c = g.cell(i, j);
-        m = fmax(m, offdiag(op, [](size_t) { return 1.0; }, c, i, j) / op.D[c]);
-    }
-    __shared__ double sm[4];
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-    if ((tid & 63) == 0) sm[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) partials[blockIdx.x] = -fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));   // negated: finished by a min
-}
-__global__ void k_min_finish1(const double *partials, int n, double *out) {
-    __shared__ double sm[256];
-    double v = INFINITY;
-    for (int t = threadIdx.x; t < n; t += 256) v = fmin(v, partials[t]);
-    sm[threadIdx.x] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = sm[0];
-}
-
-// partials: [0, NB) = |r_k|^2, and on the first pass [NB, 2NB) = |b|^2
-template <int NB>
-__global__ void k_cheb(OpDev op, Tiling T, double c1, double c2, int first, CVecs<NB> b, CVecs<NB> xk, CVecs<NB> xm,
-                       Vecs<NB> xo, double *partials) {
-    const Geo g = op.g;
-    double acc[2 * NB];
-#pragma unroll
-    for (int q = 0; q < 2 * NB; ++q) acc[q] = 0.0;
-    TILE_LOOP(g, T) {
-        const size_t c = g.cell(i, j);
-        const double d = op.D[c];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const double *xr = xk.p[q];
-            const double xc = xr[c], bq = b.p[q][c];
-            const double r = bq - (d * xc - offdiag(op, [xr](size_t n) { return xr[n]; }, c, i, j));
-            acc[q] += r * r;
-            double step = c2 * (r / d);
-            if (first) acc[NB + q] += bq * bq;
-            else step += c1 * (xc - xm.p[q][c]);
-            xo.p[q][c] = xc + step;
-        }
-    }
-    block_sums<2 * NB>(acc, partials);
-}
-
-// returns CFD_OK with *used = 0 when the system is not time-step dominated (caller falls back)
-template <int NB>
-static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
-                            double tol, int maxiter, int *iters, double relres[2], double rms[2], int *used) {
-    *used = 0;
-    if (!x0 || !c->use_chebyshev) return CFD_OK;
-    const Geo g = op.g;
-    const Tiling T = tiling(g);
-    const dim3 grid(T.blocks), blk = block2d();
-    hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_rowsum_bound, grid, blk, 0, st, op, T, c->partials);
-    hipLaunchKernelGGL(k_min_finish1, dim3(1), dim3(256), 0, st, c->partials, T.blocks, c->scal + 12);
-    CFD_HIP(hipGetLastError());
-    CFD_TRY(all_reduce(c, c->scal + 12, 1, 1));
-    // first pass: r_0, |b|^2, x_1 = x_0 + r_0 / D  (theta = 1)
-    CVecs<NB> bc, xk, xm;
-    Vecs<NB> xo;
-    double *bufA[NB], *bufB[NB];
-    for (int q = 0; q < NB; ++q) {
-        bc.p[q] = b[q];
-        // x may alias x0 (k / omega are solved in place): the passes read x_k at the neighbours, so the
-        // first iterate then goes to a work plane and the result is copied back at the end
-        bufA[q] = (x[q] == x0[q]) ? c->kry[7 + q] : x[q];
-        bufB[q] = c->kry[5 + q];
-        xk.p[q] = x0[q];
-        xm.p[q] = x0[q];
-        xo.p[q] = bufA[q];
-    }
-    c->probe_begin(8);
-    hipLaunchKernelGGL((k_cheb<NB>), grid, blk, 0, st, op, T, 0.0, 1.0, 1, bc, xk, xm, xo, c->partials);
-    c->probe_end(8);
-    CFD_HIP(hipGetLastError());
-    CFD_TRY(sum_finish(c, c->partials, T.blocks, 2 * NB, c->scal));
-    double h[5];
-    CFD_HIP(hipMemcpyAsync(c->h_scal, c->scal, 13 * sizeof(double), hipMemcpyDeviceToHost, st));
-    CFD_HIP(hipStreamSynchronize(st));
-    for (int q = 0; q < 2 * NB; ++q) h[q] = c->h_scal[q];
-    const double rho = -c->h_scal[12];
-    double rr[2] = {0, 0}, bb[2] = {0, 0};
-    for (int q = 0; q < NB; ++q) {
-        rr[q] = h[q];
-        bb[q] = h[NB + q];
-        if (!(rr[q] == rr[q]) || !(bb[q] == bb[q])) { set_error("momentum-like solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
-        if (bb[q] == 0.0 && rr[q] > 0.0) return CFD_OK;      // degenerate: leave it to BiCGStab
-    }
-    if (!(rho >= 0.0) || rho > c->cheb_rho_max) return CFD_OK;
-    auto done = [&](const double *r2) {
-        for (int q = 0; q < NB; ++q)
-            if (sqrt(r2[q]) > tol * sqrt(bb[q])) return false;
-        return true;
-    };
-    auto finish = [&](int k, double *const where[]) -> int {
-        for (int q = 0; q < NB; ++q) {
-            if (where[q] != x[q])
-                CFD_HIP(hipMemcpyAsync(x[q], where[q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
-            relres[q] = bb[q] > 0.0 ? sqrt(rr[q] / bb[q]) : 0.0;
-            if (rms) rms[q] = sqrt(rr[q] / global_cells(c));
-        }
-        *iters = k;
-        *used = 1;
-        return CFD_OK;
-    };
-    if (done(rr)) {
-        double *w[2] = {const_cast<double *>(x0[0]), const_cast<double *>(x0[NB - 1])};
-        return finish(0, w);
-    }
-    // iterations the Chebyshev bound asks for: 2 s^k / (1 + s^2k) <= tol |b| / |r_0|
-    const double sigma1 = rho > 1e-300 ? 1.0 / rho : 1e300;
-    const double s = rho > 1e-300 ? sigma1 - sqrt(sigma1 * sigma1 - 1.0) : 0.0;
-    double need = 1.0;
-    for (int q = 0; q < NB; ++q)
-        if (rr[q] > 0.0) need = fmin(need, tol * sqrt(bb[q]) / sqrt(rr[q]));
-    int kpred = 1;
-    if (s > 0.0) {
-        const double kp = log(need / 2.0) / log(s);
-        kpred = kp > 1.0 ? (kp < 1.0e6 ? (int)ceil(kp) : 1000000) : 1;
-    }
-    if (kpred > c->cheb_max_iters || kpred > maxiter) return CFD_OK;
-    // passes k = 1, 2, ...: x_k sits in A for odd k, in B for even k
-    double rk = rho;           // rho_{k-1} of Saad's Algorithm 12.1 (rho_0 = delta / theta = rho)
-    int k = 1;
-    const int klimit = std::min(maxiter, kpred + 8 + kpred / 2);
-    for (;; ++k) {
-        double **cur = (k & 1) ? bufA : bufB, **oth = (k & 1) ? bufB : bufA;
-        const double rnew = 1.0 / (2.0 * sigma1 - rk);
-        double c1 = rnew * rk, c2 = 2.0 * rnew / rho;
-        if (rho < 1.0e-14) { c1 = 0.0; c2 = 1.0; }          // diagonal matrix: x_1 was already exact
-        rk = rnew;
-        for (int q = 0; q < NB; ++q) {
-            xk.p[q] = cur[q];
-            xm.p[q] = (k == 1) ? x0[q] : oth[q];
-            xo.p[q] = oth[q];
-        }
-        CFD_TRY(halo_exchange(c, g, 1, cur[0], NB == 2 ? cur[NB - 1] : nullptr));
-        c->probe_begin(8);
-        hipLaunchKernelGGL((k_cheb<NB>), grid, blk, 0, st, op, T, c1, c2, 0, bc, xk, xm, xo, c->partials);
-        c->probe_end(8);
-        CFD_HIP(hipGetLastError());
-        if (k >= kpred || k >= klimit) {
-            // |r_k|^2 of the iterate the pass started from
-            CFD_TRY(sum_finish(c, c->partials, T.blocks, NB, c->scal));
-            double got[2];
-            CFD_TRY(read_scalars(c, 0, NB, got));
-            for (int q = 0; q < NB; ++q) {
-                rr[q] = got[q];
-                if (!(rr[q] == rr[q])) { set_error("Chebyshev: non-finite residual at iteration %d", k); return CFD_E_NUMERIC; }
-            }
-            if (done(rr)) return finish(k, cur);
-            if (k >= klimit) {
-                // bound not met (spectrum outside the interval): hand the best iterate to BiCGStab
-                for (int q = 0; q < NB; ++q)
-                    if (cur[q] != x[q])
-                        CFD_HIP(hipMemcpyAsync(x[q], cur[q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
-                *used = 2;
-                *iters = k;
-                return CFD_OK;
-            }
-        }
-    }
-}
-
-int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
-                        int nb, double tol, int maxiter, int *iters, double relres[2], double rms[2]) {
-    int used = 0, k_cheb_done = 0;
-    if (nb == 2) CFD_TRY(chebyshev_jacobi<2>(c, op, b, x, x0, tol, maxiter, &k_cheb_done, relres, rms, &used));
-    else CFD_TRY(chebyshev_jacobi<1>(c, op, b, x, x0, tol, maxiter, &k_cheb_done, relres, rms, &used));
-    c->stats_last_solver = used == 1 ? 1 : 0;
-    if (used == 1) { *iters = k_cheb_done; return CFD_OK; }
-    // used == 2: Chebyshev stalled, its last iterate (in x) is the BiCGStab starting point
-    const double *xs[2] = {x[0], x[1]};
-    const double *const *start = used == 2 ? xs : x0;
-    int it = 0;
-    int rc = nb == 2 ? bicgstab_jacobi<2>(c, op, b, x, start, tol, maxiter, &it, relres, rms)
-                     : bicgstab_jacobi<1>(c, op, b, x, start, tol, maxiter, &it, relres, rms);
-    *iters = it + (used == 2 ? k_cheb_done : 0);
-    return rc;
-}
 
 // ------------------------------------------------------------------ multigrid kernels
 // x = omega b / D   (first Jacobi sweep from a zero guess)
@@ -1008,6 +806,433 @@ static inline int march_blocks(const MarchGeo &m) {
     const long nb = (items + 3) / 4;
     return (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
 }
+
+// ------------------------------------------------------------------ Chebyshev (time-step dominated systems)
+// The transport matrices are  A = V/dt + sum a_f  on the diagonal and -a_f off it.  With
+// Jacobi scaling the spectrum of D^-1 A lies in [1 - rho, 1 + rho], rho = max_P sum_n c_n / D_P
+// (row-sum bound, rigorous).  When the step is CFL-limited rho is well below one (2/3 at
+// cfl_diff = 0.5 on a uniform mesh) and the Chebyshev semi-iteration on that interval converges
+// like CG *without any inner product*: one fused pass per iteration
+//     r_k = b - A x_k ; d_k = c1 (x_k - x_{k-1}) + c2 r_k / D ; x_{k+1} = x_k + d_k
+// (88 B/cell for two right-hand sides), |r_k|^2 falls out as a by-product and the host looks at
+// it only around the iteration the Chebyshev bound predicts.  The stopping test is the
+// reference's, |b - A x| <= tol |b| on the returned iterate.  Systems with rho close to one
+// (large dt) go to BiCGStab below.
+__global__ void k_rowsum_bound(OpDev op, Tiling T, double *partials) {
+    const Geo g = op.g;
+    double m = 0.0;
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+        m = fmax(m, offdiag(op, [](size_t) { return 1.0; }, c, i, j) / op.D[c]);
+    }
+    __shared__ double sm[4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
+    if ((tid & 63) == 0) sm[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = -fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));   // negated: finished by a min
+}
+__global__ void k_min_finish1(const double *partials, int n, double *out) {
+    __shared__ double sm[256];
+    double v = INFINITY;
+    for (int t = threadIdx.x; t < n; t += 256) v = fmin(v, partials[t]);
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// partials: [0, NB) = |r_k|^2, and on the first pass [NB, 2NB) = |b|^2
+template <int NB>
+__global__ void k_cheb(OpDev op, Tiling T, double c1, double c2, int first, CVecs<NB> b, CVecs<NB> xk, CVecs<NB> xm,
+                       Vecs<NB> xo, double *partials) {
+    const Geo g = op.g;
+    double acc[2 * NB];
+#pragma unroll
+    for (int q = 0; q < 2 * NB; ++q) acc[q] = 0.0;
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+        const double d = op.D[c];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const double *xr = xk.p[q];
+            const double xc = xr[c], bq = b.p[q][c];
+            const double r = bq - (d * xc - offdiag(op, [xr](size_t n) { return xr[n]; }, c, i, j));
+            acc[q] += r * r;
+            double step = c2 * (r / d);
+            if (first) acc[NB + q] += bq * bq;
+            else step += c1 * (xc - xm.p[q][c]);
+            xo.p[q][c] = xc + step;
+        }
+    }
+    block_sums<2 * NB>(acc, partials);
+}
+
+
+// Two Chebyshev iterations per pass, marching like the multigrid kernels above: one wavefront owns
+// a 60-column strip and walks down a row segment with x_k, x_{k+1} and the operator rows in
+// registers.  Per cell and launch it reads x_k, x_{k-1}, b (per right-hand side) and D, c_i, c_j once
+// and writes x_{k+1}, x_{k+2}: 104 B for two iterations of two right-hand sides (the one-iteration
+// kernel above moves 88 B per iteration).  |r_k|^2, |r_{k+1}|^2 (and |b|^2 on the first launch) come
+// out as partial sums [q], [NB + q], [2 NB + q].
+struct RowA {
+    double d, inv, cw, ce, cs, cn;
+};
+template <int NB>
+__global__ __launch_bounds__(256) void k_cheb2(OpDev op, MarchGeo mg, double c1a, double c2a, double c1b, double c2b,
+                                               int first, CVecs<NB> b, CVecs<NB> xk, CVecs<NB> xm, Vecs<NB> x1o,
+                                               Vecs<NB> x2o, double *partials) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    double acc[3 * NB];
+#pragma unroll
+    for (int q = 0; q < 3 * NB; ++q) acc[q] = 0.0;
+    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+        const int iraw = strip * MW - MH + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        // row j: operator row + x_k ; returns the cell index (clamped to a valid cell when outside)
+        auto load = [&](int j, bool &valid, RowA &a, double (&xv)[NB]) -> size_t {
+            const int mr = mem_row(j, g, op.per_j);
+            valid = cvalid && mr >= 0;
+            const size_t c = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+            a.d = op.D[c]; a.cw = op.ci[c]; a.ce = op.ci[c + 1]; a.cs = op.cj[c]; a.cn = op.cj[c + (mr < g.nj + 3 ? P : 0)];
+            a.inv = fast_rcp(a.d);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) xv[q] = valid ? xk.p[q][c] : 0.0;
+            return c;
+        };
+        RowA ra0, ra1, ra2;
+        double xa[NB], xb[NB], xc[NB], ya[NB], yb[NB], yc[NB], b2[NB];
+        bool v0, v1, v2;
+        size_t cell1, cell2 = 0;
+        load(j0 - 2, v2, ra2, xa);
+        cell1 = load(j0 - 1, v1, ra1, xb);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) { ya[q] = 0.0; yb[q] = 0.0; yc[q] = 0.0; b2[q] = 0.0; }
+        for (int j = j0; j < j1 + 2; ++j) {
+            const size_t cell0 = load(j, v0, ra0, xc);
+            const bool in1 = j - 1 >= j0 && j - 1 < j1 && out, in2 = j - 2 >= j0 && j - 2 < j1 && out;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                // first iteration on row j-1
+                const double bq = b.p[q][cell1];
+                const double xl = lane_left(xb[q]), xr = lane_right(xb[q]);
+                const double r = bq - (ra1.d * xb[q] - (ra1.cw * xl + ra1.ce * xr + ra1.cs * xa[q] + ra1.cn * xc[q]));
+                double step = c2a * (r * ra1.inv);
+                if (!first) step += c1a * (xb[q] - xm.p[q][cell1]);
+                yc[q] = v1 ? xb[q] + step : 0.0;
+                if (in1) {
+                    x1o.p[q][cell1] = yc[q];
+                    acc[q] += r * r;
+                    if (first) acc[2 * NB + q] += bq * bq;
+                }
+                // second iteration on row j-2
+                const double yl = lane_left(yb[q]), yr = lane_right(yb[q]);
+                const double r2 = b2[q] - (ra2.d * yb[q] - (ra2.cw * yl + ra2.ce * yr + ra2.cs * ya[q] + ra2.cn * yc[q]));
+                if (in2) {
+                    x2o.p[q][cell2] = yb[q] + c1b * (yb[q] - xa[q]) + c2b * (r2 * ra2.inv);
+                    acc[NB + q] += r2 * r2;
+                }
+                xa[q] = xb[q]; xb[q] = xc[q];
+                ya[q] = yb[q]; yb[q] = yc[q];
+                b2[q] = bq;
+            }
+            ra2 = ra1; ra1 = ra0;
+            v2 = v1; v1 = v0;
+            cell2 = cell1; cell1 = cell0;
+        }
+    }
+    __shared__ double sm[3 * NB][4];
+#pragma unroll
+    for (int q = 0; q < 3 * NB; ++q) {
+        const double w = wsum(acc[q]);
+        if (lane == 0) sm[q][wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * NB)
+        partials[(size_t)threadIdx.x * MAX_PARTIALS + blockIdx.x] =
+            (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
+// Chebyshev coefficient stream of Saad's Algorithm 12.1 on [1 - rho, 1 + rho]
+struct ChebCoef {
+    double rho, sigma1, rk;
+    int k = 0;
+    explicit ChebCoef(double rho_) : rho(rho_), sigma1(rho_ > 1e-300 ? 1.0 / rho_ : 1e300), rk(rho_) {}
+    // coefficients of iteration k -> k+1:  x_{k+1} = x_k + c1 (x_k - x_{k-1}) + c2 r_k / D
+    void next(double &c1, double &c2) {
+        if (k == 0) { c1 = 0.0; c2 = 1.0; }
+        else {
+            const double rnew = 1.0 / (2.0 * sigma1 - rk);
+            c1 = rnew * rk; c2 = 2.0 * rnew / rho;
+            if (rho < 1.0e-14) { c1 = 0.0; c2 = 1.0; }     // diagonal matrix: x_1 was already exact
+            rk = rnew;
+        }
+        ++k;
+    }
+    // iterations the bound 2 s^k / (1 + s^2k) <= need asks for
+    int predict(double need) const {
+        const double s = rho > 1e-300 ? sigma1 - sqrt(sigma1 * sigma1 - 1.0) : 0.0;
+        if (!(s > 0.0) || !(need < 1.0)) return 1;
+        const double kp = log(need / 2.0) / log(s);
+        return kp > 1.0 ? (kp < 1.0e6 ? (int)ceil(kp) : 1000000) : 1;
+    }
+};
+
+template <int NB>
+static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
+                           double tol, int maxiter, int *iters, double relres[2], double rms[2], int *used) {
+    const Geo g = op.g;
+    hipStream_t st = c->stream;
+    const MarchGeo mgeo = march_geo(g);
+    const dim3 grid(march_blocks(mgeo));
+    // iterate buffers: launch m writes x_{2m-1}, x_{2m} into set m & 1 and reads set (m - 1) & 1
+    double *set[2][2][NB];
+    CVecs<NB> bc;
+    for (int q = 0; q < NB; ++q) {
+        bc.p[q] = b[q];
+        set[1][0][q] = (x[q] == x0[q]) ? c->kry[11 + q] : x[q];     // x may alias x0 (k / omega)
+        set[1][1][q] = c->kry[5 + q];
+        set[0][0][q] = c->kry[7 + q];
+        set[0][1][q] = c->kry[9 + q];
+    }
+    if (c->comm.nranks > 1) {
+        // the two fused iterations read two rows across a cut
+        CFD_TRY(halo_exchange(c, g, 2, const_cast<double *>(op.ci), const_cast<double *>(op.cj), const_cast<double *>(op.D)));
+        CFD_TRY(halo_exchange(c, g, 1, b[0], NB == 2 ? b[NB - 1] : nullptr));
+        CFD_TRY(halo_exchange(c, g, 2, const_cast<double *>(x0[0]), NB == 2 ? const_cast<double *>(x0[NB - 1]) : nullptr));
+    }
+    const double rho = -c->h_scal[12];
+    ChebCoef cc(rho);
+    double bb[2] = {0, 0};
+    auto done = [&](const double *r2) {
+        for (int q = 0; q < NB; ++q)
+            if (sqrt(r2[q]) > tol * sqrt(bb[q])) return false;
+        return true;
+    };
+    auto finish = [&](int k, const double *r2, double *const where[]) -> int {
+        for (int q = 0; q < NB; ++q) {
+            if (where[q] != x[q])
+                CFD_HIP(hipMemcpyAsync(x[q], where[q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+            relres[q] = bb[q] > 0.0 ? sqrt(r2[q] / bb[q]) : 0.0;
+            if (rms) rms[q] = sqrt(r2[q] / global_cells(c));
+        }
+        *iters = k;
+        *used = 1;
+        return CFD_OK;
+    };
+    int kpred = 1, klimit = maxiter;
+    for (int m = 1;; ++m) {
+        CVecs<NB> xk, xm;
+        Vecs<NB> o1, o2;
+        double *cur_k[NB], *cur_m[NB];
+        for (int q = 0; q < NB; ++q) {
+            cur_k[q] = m == 1 ? const_cast<double *>(x0[q]) : set[(m - 1) & 1][1][q];
+            cur_m[q] = m == 1 ? const_cast<double *>(x0[q]) : set[(m - 1) & 1][0][q];
+            xk.p[q] = cur_k[q]; xm.p[q] = cur_m[q];
+            o1.p[q] = set[m & 1][0][q]; o2.p[q] = set[m & 1][1][q];
+        }
+        if (m > 1 && c->comm.nranks > 1) {
+            CFD_TRY(halo_exchange(c, g, 2, cur_k[0], NB == 2 ? cur_k[NB - 1] : nullptr));
+            CFD_TRY(halo_exchange(c, g, 1, cur_m[0], NB == 2 ? cur_m[NB - 1] : nullptr));
+        }
+        double c1a, c2a, c1b, c2b;
+        cc.next(c1a, c2a);
+        cc.next(c1b, c2b);
+        c->probe_begin(8);
+        hipLaunchKernelGGL((k_cheb2<NB>), grid, dim3(256), 0, st, op, mgeo, c1a, c2a, c1b, c2b, m == 1 ? 1 : 0, bc, xk, xm,
+                           o1, o2, c->partials);
+        c->probe_end(8);
+        CFD_HIP(hipGetLastError());
+        const int k0 = 2 * m - 2;                  // this launch measured |r_k0| and |r_{k0+1}|
+        if (m == 1 || k0 + 1 >= kpred || k0 + 1 >= klimit) {
+            const int nq = m == 1 ? 3 * NB : 2 * NB;
+            CFD_TRY(sum_finish(c, c->partials, (int)grid.x, nq, c->scal));
+            double got[6];
+            CFD_TRY(read_scalars(c, 0, nq, got));
+            for (int q = 0; q < nq; ++q)
+                if (!(got[q] == got[q])) { set_error("Chebyshev: non-finite residual near iteration %d", k0); return CFD_E_NUMERIC; }
+            if (m == 1) {
+                double need = 1.0;
+                for (int q = 0; q < NB; ++q) {
+                    bb[q] = got[2 * NB + q];
+                    if (bb[q] == 0.0 && got[q] > 0.0) return CFD_OK;     // degenerate: leave it to BiCGStab
+                    if (got[q] > 0.0) need = fmin(need, tol * sqrt(bb[q]) / sqrt(got[q]));
+                }
+                kpred = cc.predict(need);
+                if (!done(got) && (kpred > c->cheb_max_iters || kpred > maxiter)) return CFD_OK;
+                klimit = std::min(maxiter, kpred + 8 + kpred / 2);
+            }
+            if (done(got)) return finish(k0, got, cur_k);
+            if (done(got + NB)) return finish(k0 + 1, got + NB, set[m & 1][0]);
+            if (k0 + 1 >= klimit) {
+                // bound not met (spectrum outside the interval): hand the newest iterate to BiCGStab
+                for (int q = 0; q < NB; ++q)
+                    if (set[m & 1][1][q] != x[q])
+                        CFD_HIP(hipMemcpyAsync(x[q], set[m & 1][1][q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+                *used = 2;
+                *iters = k0 + 2;
+                return CFD_OK;
+            }
+        }
+    }
+}
+
+// returns CFD_OK with *used = 0 when the system is not time-step dominated (caller falls back)
+template <int NB>
+static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
+                            double tol, int maxiter, int *iters, double relres[2], double rms[2], int *used) {
+    *used = 0;
+    if (!x0 || !c->use_chebyshev) return CFD_OK;
+    const Geo g = op.g;
+    const Tiling T = tiling(g);
+    const dim3 grid(T.blocks), blk = block2d();
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_rowsum_bound, grid, blk, 0, st, op, T, c->partials);
+    hipLaunchKernelGGL(k_min_finish1, dim3(1), dim3(256), 0, st, c->partials, T.blocks, c->scal + 12);
+    CFD_HIP(hipGetLastError());
+    CFD_TRY(all_reduce(c, c->scal + 12, 1, 1));
+    if (c->mg_fused && g.ni >= 16 && g.nj >= 16) {
+        CFD_TRY(read_scalars(c, 12, 1, c->h_scal + 12));      // h_scal[12] = -rho
+        const double rho_f = -c->h_scal[12];
+        if (!(rho_f >= 0.0) || rho_f > c->cheb_rho_max) return CFD_OK;
+        return chebyshev_fused<NB>(c, op, b, x, x0, tol, maxiter, iters, relres, rms, used);
+    }
+    // first pass: r_0, |b|^2, x_1 = x_0 + r_0 / D  (theta = 1)
+    CVecs<NB> bc, xk, xm;
+    Vecs<NB> xo;
+    double *bufA[NB], *bufB[NB];
+    for (int q = 0; q < NB; ++q) {
+        bc.p[q] = b[q];
+        // x may alias x0 (k / omega are solved in place): the passes read x_k at the neighbours, so the
+        // first iterate then goes to a work plane and the result is copied back at the end
+        bufA[q] = (x[q] == x0[q]) ? c->kry[7 + q] : x[q];
+        bufB[q] = c->kry[5 + q];
+        xk.p[q] = x0[q];
+        xm.p[q] = x0[q];
+        xo.p[q] = bufA[q];
+    }
+    c->probe_begin(8);
+    hipLaunchKernelGGL((k_cheb<NB>), grid, blk, 0, st, op, T, 0.0, 1.0, 1, bc, xk, xm, xo, c->partials);
+    c->probe_end(8);
+    CFD_HIP(hipGetLastError());
+    CFD_TRY(sum_finish(c, c->partials, T.blocks, 2 * NB, c->scal));
+    double h[5];
+    CFD_HIP(hipMemcpyAsync(c->h_scal, c->scal, 13 * sizeof(double), hipMemcpyDeviceToHost, st));
+    CFD_HIP(hipStreamSynchronize(st));
+    for (int q = 0; q < 2 * NB; ++q) h[q] = c->h_scal[q];
+    const double rho = -c->h_scal[12];
+    double rr[2] = {0, 0}, bb[2] = {0, 0};
+    for (int q = 0; q < NB; ++q) {
+        rr[q] = h[q];
+        bb[q] = h[NB + q];
+        if (!(rr[q] == rr[q]) || !(bb[q] == bb[q])) { set_error("momentum-like solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
+        if (bb[q] == 0.0 && rr[q] > 0.0) return CFD_OK;      // degenerate: leave it to BiCGStab
+    }
+    if (!(rho >= 0.0) || rho > c->cheb_rho_max) return CFD_OK;
+    auto done = [&](const double *r2) {
+        for (int q = 0; q < NB; ++q)
+            if (sqrt(r2[q]) > tol * sqrt(bb[q])) return false;
+        return true;
+    };
+    auto finish = [&](int k, double *const where[]) -> int {
+        for (int q = 0; q < NB; ++q) {
+            if (where[q] != x[q])
+                CFD_HIP(hipMemcpyAsync(x[q], where[q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+            relres[q] = bb[q] > 0.0 ? sqrt(rr[q] / bb[q]) : 0.0;
+            if (rms) rms[q] = sqrt(rr[q] / global_cells(c));
+        }
+        *iters = k;
+        *used = 1;
+        return CFD_OK;
+    };
+    if (done(rr)) {
+        double *w[2] = {const_cast<double *>(x0[0]), const_cast<double *>(x0[NB - 1])};
+        return finish(0, w);
+    }
+    // iterations the Chebyshev bound asks for: 2 s^k / (1 + s^2k) <= tol |b| / |r_0|
+    const double sigma1 = rho > 1e-300 ? 1.0 / rho : 1e300;
+    const double s = rho > 1e-300 ? sigma1 - sqrt(sigma1 * sigma1 - 1.0) : 0.0;
+    double need = 1.0;
+    for (int q = 0; q < NB; ++q)
+        if (rr[q] > 0.0) need = fmin(need, tol * sqrt(bb[q]) / sqrt(rr[q]));
+    int kpred = 1;
+    if (s > 0.0) {
+        const double kp = log(need / 2.0) / log(s);
+        kpred = kp > 1.0 ? (kp < 1.0e6 ? (int)ceil(kp) : 1000000) : 1;
+    }
+    if (kpred > c->cheb_max_iters || kpred > maxiter) return CFD_OK;
+    // passes k = 1, 2, ...: x_k sits in A for odd k, in B for even k
+    double rk = rho;           // rho_{k-1} of Saad's Algorithm 12.1 (rho_0 = delta / theta = rho)
+    int k = 1;
+    const int klimit = std::min(maxiter, kpred + 8 + kpred / 2);
+    for (;; ++k) {
+        double **cur = (k & 1) ? bufA : bufB, **oth = (k & 1) ? bufB : bufA;
+        const double rnew = 1.0 / (2.0 * sigma1 - rk);
+        double c1 = rnew * rk, c2 = 2.0 * rnew / rho;
+        if (rho < 1.0e-14) { c1 = 0.0; c2 = 1.0; }          // diagonal matrix: x_1 was already exact
+        rk = rnew;
+        for (int q = 0; q < NB; ++q) {
+            xk.p[q] = cur[q];
+            xm.p[q] = (k == 1) ? x0[q] : oth[q];
+            xo.p[q] = oth[q];
+        }
+        CFD_TRY(halo_exchange(c, g, 1, cur[0], NB == 2 ? cur[NB - 1] : nullptr));
+        c->probe_begin(8);
+        hipLaunchKernelGGL((k_cheb<NB>), grid, blk, 0, st, op, T, c1, c2, 0, bc, xk, xm, xo, c->partials);
+        c->probe_end(8);
+        CFD_HIP(hipGetLastError());
+        if (k >= kpred || k >= klimit) {
+            // |r_k|^2 of the iterate the pass started from
+            CFD_TRY(sum_finish(c, c->partials, T.blocks, NB, c->scal));
+            double got[2];
+            CFD_TRY(read_scalars(c, 0, NB, got));
+            for (int q = 0; q < NB; ++q) {
+                rr[q] = got[q];
+                if (!(rr[q] == rr[q])) { set_error("Chebyshev: non-finite residual at iteration %d", k); return CFD_E_NUMERIC; }
+            }
+            if (done(rr)) return finish(k, cur);
+            if (k >= klimit) {
+                // bound not met (spectrum outside the interval): hand the best iterate to BiCGStab
+                for (int q = 0; q < NB; ++q)
+                    if (cur[q] != x[q])
+                        CFD_HIP(hipMemcpyAsync(x[q], cur[q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+                *used = 2;
+                *iters = k;
+                return CFD_OK;
+            }
+        }
+    }
+}
+
+int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
+                        int nb, double tol, int maxiter, int *iters, double relres[2], double rms[2]) {
+    int used = 0, k_cheb_done = 0;
+    if (nb == 2) CFD_TRY(chebyshev_jacobi<2>(c, op, b, x, x0, tol, maxiter, &k_cheb_done, relres, rms, &used));
+    else CFD_TRY(chebyshev_jacobi<1>(c, op, b, x, x0, tol, maxiter, &k_cheb_done, relres, rms, &used));
+    c->stats_last_solver = used == 1 ? 1 : 0;
+    if (used == 1) { *iters = k_cheb_done; return CFD_OK; }
+    // used == 2: Chebyshev stalled, its last iterate (in x) is the BiCGStab starting point
+    const double *xs[2] = {x[0], x[1]};
+    const double *const *start = used == 2 ? xs : x0;
+    int it = 0;
+    int rc = nb == 2 ? bicgstab_jacobi<2>(c, op, b, x, start, tol, maxiter, &it, relres, rms)
+                     : bicgstab_jacobi<1>(c, op, b, x, start, tol, maxiter, &it, relres, rms);
+    *iters = it + (used == 2 ? k_cheb_done : 0);
+    return rc;
+}
+
 
 static inline OpDev level_op(const Ctx *c, const Level &L) {
     return OpDev{L.ci, L.cj, L.D, L.g, c->pp_per_i, c->pp_per_j};
