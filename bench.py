@@ -9,10 +9,14 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
     torchrun ... bench.py --gpus N ...                        (one rank per GPU)
 
 The JSON line also carries
-  roofline     : the finest-level multigrid smoother kernel k_mg_up<true> (prolongation + two
-                 fused damped-Jacobi sweeps + the PCG dot product in one pass), timed live with
-                 HIP-event pairs around every launch inside the timed steps; achieved =
-                 50 B/cell * Ni*Nj / avg duration (x, e/4, b, c_i, c_j, D read + x' written).
+  roofline     : the kernel with the largest share of device time, k_cheb2<2> (two Chebyshev
+                 iterations of the u and v momentum systems per launch), timed live with HIP-event
+                 pairs around every launch inside the timed steps; achieved = 104 B/cell * Ni*Nj /
+                 avg duration (x_k, x_{k-1}, b of u and v + D, c_i, c_j read; x_{k+1}, x_{k+2} of u
+                 and v written).  --probe 7 / 1 / 0 select the multigrid up / down kernels / the
+                 pressure SpMV instead.  traffic = HBM bytes per launch from the committed PMC passes
+                 of this command (profiles/r1d_pmc8192_bytes_per_cell.csv), quoted only at the
+                 default size they were measured on.
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
                  factor-once LU pressure) timed on this host, bounded sample.
 """
@@ -32,6 +36,9 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 50   # k_mg_up: x, e/4, b, c_i, c_j, D read + x' written, for TWO sweeps + prolongation
+# HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
+# 8192^2 (profiles/r1d_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {8: 108.30, 7: 56.09, 1: 45.92, 0: 43.17, 2: 140.16}
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1):
@@ -110,7 +117,9 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--probe", type=int, default=7, help="kernel id for the live roofline probe")
+    ap.add_argument("--probe", type=int, default=8, help="kernel id for the live roofline probe")
+    ap.add_argument("--mg-omega", type=float, default=None, help="smoother damping of the even sweeps")
+    ap.add_argument("--mg-omega2", type=float, default=None, help="smoother damping of the odd sweeps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use GPU 0 (with --backend gloo), numbers are not a measurement")
@@ -142,6 +151,8 @@ def main():
 
     n = args.size
     dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, world)
+    if args.mg_omega is not None or args.mg_omega2 is not None:
+        dev.set_multigrid(omega=args.mg_omega or 0.8, omega2=args.mg_omega2 or 0.0)
     step = 0
     iters = []
     for _ in range(args.warmup):
@@ -178,7 +189,10 @@ def main():
         bytes_per_cell = {0: 40, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]
         achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": (PMC_TRAFFIC_BYTES_PER_CELL_8192[args.probe] * n * n
+                                if n == 8192 and not args.turbulent and args.probe in PMC_TRAFFIC_BYTES_PER_CELL_8192 else None),
+                    "traffic_unit": "bytes per launch (PMC, committed profile)",
                     "kernel": kernel_names.get(args.probe, str(args.probe)),
                     "avg_us": probe_us, "launches_timed": n_probe, "bytes_per_cell": bytes_per_cell}
         it = np.array(iters)

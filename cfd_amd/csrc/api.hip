@@ -525,6 +525,13 @@ int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double
     return CFD_OK;
 }
 
+int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2) {
+    CTX(ctx);
+    if (omega2 > 2.0) { set_error("cfd_set_smoother_omega2: omega2 must be <= 2"); return CFD_E_ARG; }
+    c->mg_omega2 = omega2;
+    return CFD_OK;
+}
+
 int cfd_set_turbulence_clip(cfd_ctx *ctx, double k_min, double omega_min) {
     CTX(ctx);
     c->k_clip = k_min; c->omega_clip = omega_min;

@@ -164,7 +164,7 @@ struct Ctx {
     double mom_tol = 1e-8, p_tol = 1e-8, turb_tol = 1e-8;
     int mom_maxiter = 200, p_maxiter = 200, turb_maxiter = 200, freeze_pressure = 1;
     int mg_pre = 2, mg_post = 2, mg_coarse_sweeps = 40, mg_min = 4;
-    double mg_omega = 0.8;
+    double mg_omega = 0.8, mg_omega2 = 0.0;   // omega2 <= 0: same damping on every sweep
     int warm_start = 1;          // Krylov initial guess = previous field (reference: zero)
     int use_chebyshev = 1;       // Chebyshev semi-iteration for time-step dominated transport systems
     double cheb_rho_max = 0.95;  // ... i.e. Jacobi row-sum bound below this

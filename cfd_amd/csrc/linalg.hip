@@ -671,7 +671,7 @@ static inline MarchGeo march_geo(const Geo &g) {
 }
 
 template <bool FINE>
-__global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const double *b, double omega, double *x, Geo gc,
+__global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const double *b, double omega, double omega2, double *x, Geo gc,
                                                  double *bc) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
                 const RowC rc0 = rn[q];
                 x1c = vn[q] ? omega * rc0.b * rc0.inv : 0.0;
                 // second sweep on row j-1
-                x2c = jac(x1b, x1a, x1c, rc1, omega);
+                x2c = jac(x1b, x1a, x1c, rc1, omega2);
                 if (!v1) x2c = 0.0;                   // outside the domain: x = 0
                 if (j - 1 >= j0 && j - 1 < j1 && out) x[(size_t)(j + 1) * P + colo] = x2c;
                 // residual on row j-2
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
 
 template <bool FINE>
 __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const double *b, const double *x, Geo gc,
-                                               const double *e, double omega, double *xn, double *partials) {
+                                               const double *e, double omega, double omega2, double *xn, double *partials) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const doub
                 if (!v1) x1c = 0.0;
                 // second sweep on row j-2
                 const int jo = j - 2;
-                const double x2 = jac(x1b, x1a, x1c, rc2, omega);
+                const double x2 = jac(x1b, x1a, x1c, rc2, omega2);
                 if (jo >= j0 && jo < j1 && out) {
                     xn[(size_t)(jo + 2) * P + colo] = x2;
                     if (FINE) dot += rc2.b * x2;
@@ -1323,7 +1323,9 @@ int build_pressure_hierarchy(Ctx *c) {
 static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks) {
     hipStream_t st = c->stream;
     const int nl = (int)c->levels.size();
-    const double om = c->mg_omega;
+    // sweep s of a smoothing pass uses omega (even s) or omega2 (odd s): with omega2 != omega the two
+    // sweeps form the degree-2 Chebyshev polynomial smoother on the upper part of the Jacobi spectrum
+    const double om = c->mg_omega, om2 = c->mg_omega2 > 0.0 ? c->mg_omega2 : c->mg_omega;
     const int pre = c->mg_pre < 1 ? 1 : c->mg_pre, post = c->mg_post;
     std::vector<double *> cur(nl), oth(nl);
     std::vector<const double *> rhs(nl);
@@ -1346,10 +1348,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             CFD_TRY(halo_exchange(c, L.g, 2, const_cast<double *>(rhs[l])));
             if (l == 0) {
                 c->probe_begin(1);
-                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], cg, cb);
+                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, om2, cur[l], cg, cb);
                 c->probe_end(1);
             } else {
-                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, cur[l], cg, cb);
+                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, om2, cur[l], cg, cb);
             }
             CFD_HIP(hipGetLastError());
         } else {
@@ -1357,7 +1359,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
             for (int s = 1; s < pre; ++s) {
                 CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
-                hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
+                hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], (s & 1) ? om2 : om, oth[l]);
                 std::swap(cur[l], oth[l]);
             }
             CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
@@ -1403,12 +1405,12 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             CFD_TRY(halo_exchange(c, L.g, 2, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
-                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om,
+                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om, om2,
                                    oth[l], c->partials);
                 c->probe_end(7);
                 *dot_blocks = (int)grid.x;
             } else {
-                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om,
+                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om, om2,
                                    oth[l], c->partials);
             }
             std::swap(cur[l], oth[l]);
@@ -1421,7 +1423,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, cg, fi, fj, e, cur[l]);
         for (int s = 0; s < post; ++s) {
             CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
-            hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], om, oth[l]);
+            hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], (s & 1) ? om2 : om, oth[l]);
             std::swap(cur[l], oth[l]);
         }
         CFD_HIP(hipGetLastError());
@@ -1649,7 +1651,7 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                     if (c->levels.size() > 1 && level_fusable(c, c->levels[0].g, coarse_view(c, 1))) {
                         const MarchGeo mgeo = march_geo(g);
                         hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->kry[1],
-                                           c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_omega, c->kry[5], c->partials);
+                                           c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_omega, c->mg_omega, c->kry[5], c->partials);
                     } else {
                         hipLaunchKernelGGL(k_mg_jacobi, grid, blk, 0, st, op, T, c->kry[1], c->kry[4], c->mg_omega, c->kry[5]);
                     }

@@ -151,9 +151,10 @@ class Device:
         check(self.lib.cfd_set_solver(self._h, float(mom_tol), int(mom_maxiter), float(p_tol), int(p_maxiter),
                                       float(turb_tol), int(turb_maxiter), int(bool(freeze_pressure))))
 
-    def set_multigrid(self, nu_pre=2, nu_post=2, omega=0.8, coarse_sweeps=40, fused=True):
+    def set_multigrid(self, nu_pre=2, nu_post=2, omega=0.8, coarse_sweeps=40, fused=True, omega2=0.0):
         check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(omega), int(coarse_sweeps),
                                          int(bool(fused))))
+        check(self.lib.cfd_set_smoother_omega2(self._h, float(omega2)))
 
     def set_transport_solver(self, warm_start=True, chebyshev=True, rho_max=0.95, max_iters=80):
         check(self.lib.cfd_set_transport_solver(self._h, int(bool(warm_start)), int(bool(chebyshev)), float(rho_max),

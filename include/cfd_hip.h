@@ -163,6 +163,11 @@ int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, 
 /* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps; fused = 1 uses
  * the temporally blocked (two sweeps per pass) marching kernels when nu_pre = nu_post = 2  */
 int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused);
+/* Damping of the odd smoothing sweeps (the even ones use `omega` of cfd_set_multigrid).  omega = 0.5617,
+ * omega2 = 1.3895 make two sweeps the degree-2 Chebyshev smoother on [0.5, 2] of the Jacobi-scaled
+ * spectrum; omega2 <= 0 (default): plain damped Jacobi.  The single-block coarsest solve always uses
+ * `omega`.  (Replaces pyamg's smoother choice, solver.py:821-833.)                                  */
+int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
 /* Transport (momentum, k-omega) solver policy; replaces the reference's spilu + scipy bicgstab
  * with x0 = 0 (solver.py:785-818), same stopping test |b - A x| <= tol |b|.
  *   warm_start : start from the previous field instead of zero;
