@@ -160,6 +160,7 @@ def main():
         step += 1
     dev.synchronize()
     dev.probe(args.probe)
+    comm0 = (dev.comm.n_halo, dev.comm.n_reduce, dev.comm.n_gather) if dev.comm is not None else (0, 0, 0)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -208,6 +209,9 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel (height {world}), halo exchange + "
                        f"all-reduce over RCCL, coarse multigrid levels replicated",
+                       "collectives_per_step": None if dev.comm is None else dict(zip(
+                           ("halo_exchanges", "all_reduces", "all_gathers"),
+                           [(a - b) / args.steps for a, b in zip((dev.comm.n_halo, dev.comm.n_reduce, dev.comm.n_gather), comm0)])),
                        "inner_iterations": args.max_iter,
                        "mean_momentum_iters": float(it[:, 0].mean()), "mean_pressure_iters": float(it[:, 1].mean()),
                        "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,

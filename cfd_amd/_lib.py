@@ -104,8 +104,8 @@ HALO_FN = C.CFUNCTYPE(C.c_int, _vp, C.c_int, C.POINTER(_vp), C.c_int, C.c_int, C
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_int, C.c_int)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_size_t)
 SIGNATURES.update({
-    "cfd_workspace_bytes_slab": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "cfd_create_slab": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int]),
+    "cfd_workspace_bytes_slab": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "cfd_create_slab": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "cfd_set_comm": (C.c_int, [_vp, HALO_FN, ALLREDUCE_FN, ALLGATHER_FN, _vp]),
     "cfd_exchange_field": (C.c_int, [_vp, C.c_int]),
     "cfd_level_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

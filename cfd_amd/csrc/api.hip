@@ -111,8 +111,9 @@ static std::vector<Geo> level_geometry(int ni, int nj) {
 // j-slab hierarchy: levels [0, l_agg) are slabs of nj_local / 2^l rows (exact 2x coarsening in j so
 // that aggregates never straddle a cut), level l_agg is the first replicated one: the global level
 // (all slabs gathered), coarsened further like a single-rank hierarchy.  Slab levels stop when the
-// slab would drop below 16 rows or an odd row count: below that the exchanges are pure latency.
-static std::vector<Geo> level_geometry_slab(int ni, int nj_loc, int nranks, int rank, int &l_agg, Geo &gs) {
+// slab would drop below min_rows rows (>= 16) or to an odd row count: below that the three exchanges a
+// level costs per V-cycle are pure latency, while replicating the level costs nranks times its (small) work.
+static std::vector<Geo> level_geometry_slab(int ni, int nj_loc, int nranks, int rank, int min_rows, int &l_agg, Geo &gs) {
     std::vector<Geo> out;
     const int mg_min = 4;
     Geo g{ni, nj_loc, pitch_for(ni), rank > 0, rank < nranks - 1};
@@ -121,7 +122,7 @@ static std::vector<Geo> level_geometry_slab(int ni, int nj_loc, int nranks, int 
         const Geo f = out.back();
         const int ci = f.ni > mg_min ? (f.ni + 1) / 2 : f.ni;
         const int cj = f.nj / 2;                       // f.nj is even by construction
-        if (cj % 2 == 0 && cj >= 16 && (int)out.size() < MAX_LEVELS / 2) {
+        if (cj % 2 == 0 && cj >= min_rows && (int)out.size() < MAX_LEVELS / 2) {
             out.push_back(Geo{ci, cj, pitch_for(ci), g.cutlo, g.cuthi});
             continue;
         }
@@ -138,10 +139,10 @@ static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 constexpr int N_FINE_PLANES = 12 + 6 + 3 + 4 + 3 + 3 + 2 + 2 + 16 + 3;
 constexpr size_t MISC_BYTES = (size_t)8 * MAX_PARTIALS * sizeof(double) + 4096;
 
-static size_t workspace_bytes_impl(int ni, int nj, int nranks, size_t bc_bytes) {
+static size_t workspace_bytes_impl(int ni, int nj, int nranks, int min_rows, size_t bc_bytes) {
     int l_agg = 0;
     Geo gs{};
-    const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, 0, l_agg, gs) : level_geometry(ni, nj);
+    const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, 0, min_rows, l_agg, gs) : level_geometry(ni, nj);
     size_t total = (size_t)N_FINE_PLANES * align256(lv[0].plane_elems() * sizeof(double));
     for (size_t l = 1; l < lv.size(); ++l) total += 6 * align256(lv[l].plane_elems() * sizeof(double));
     if (nranks > 1) total += 3 * align256(gs.plane_elems() * sizeof(double));
@@ -190,21 +191,24 @@ int cfd_version(void) { return 100; }
 
 size_t cfd_workspace_bytes(int ni, int nj) {
     if (ni < 1 || nj < 1) return 0;
-    return workspace_bytes_impl(ni, nj, 1, bc_bytes_for(ni, nj));
+    return workspace_bytes_impl(ni, nj, 1, 16, bc_bytes_for(ni, nj));
 }
 
-size_t cfd_workspace_bytes_slab(int ni, int nj_local, int nranks) {
-    if (ni < 1 || nj_local < 2 || nranks < 1 || (nranks > 1 && nj_local % 2)) return 0;
-    return workspace_bytes_impl(ni, nj_local, nranks, bc_bytes_for(ni, nj_local));
+size_t cfd_workspace_bytes_slab(int ni, int nj_local, int nranks, int min_slab_rows) {
+    if (ni < 1 || nj_local < 2 || nranks < 1 || (nranks > 1 && nj_local % 2) || min_slab_rows < 16) return 0;
+    return workspace_bytes_impl(ni, nj_local, nranks, min_slab_rows, bc_bytes_for(ni, nj_local));
 }
 
 int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes) {
-    return cfd_create_slab(out, ni, nj, device, workspace, workspace_bytes, 0, 1);
+    return cfd_create_slab(out, ni, nj, device, workspace, workspace_bytes, 0, 1, 16);
 }
 
 int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes, int rank,
-                    int nranks) {
-    if (!out || ni < 1 || nj < 1 || nranks < 1 || rank < 0 || rank >= nranks) { set_error("cfd_create: bad arguments"); return CFD_E_ARG; }
+                    int nranks, int min_slab_rows) {
+    if (!out || ni < 1 || nj < 1 || nranks < 1 || rank < 0 || rank >= nranks || min_slab_rows < 16) {
+        set_error("cfd_create: bad arguments");
+        return CFD_E_ARG;
+    }
     if (nranks > 1 && (nj % 2 || nj < 4)) {
         set_error("j-slab contexts need an even number (>= 4) of local rows, got %d", nj);
         return CFD_E_ARG;
@@ -214,7 +218,7 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     if (!h) { set_error("out of host memory"); return CFD_E_ARG; }
     Ctx *c = &h->c;
     c->device = device;
-    const size_t need = cfd_workspace_bytes_slab(ni, nj, nranks);
+    const size_t need = cfd_workspace_bytes_slab(ni, nj, nranks, min_slab_rows);
     if (workspace) {
         if (workspace_bytes < need || ((uintptr_t)workspace & 255)) {
             set_error("workspace too small or not 256-byte aligned (need %zu bytes)", need);
@@ -236,7 +240,8 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     if (e != hipSuccess) { set_error("hipMemset failed"); return CFD_E_HIP; }
 
     Geo gs{};
-    const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, rank, c->l_agg, gs) : level_geometry(ni, nj);
+    const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, rank, min_slab_rows, c->l_agg, gs)
+                                           : level_geometry(ni, nj);
     c->comm.rank = rank; c->comm.nranks = nranks; c->comm.nj_global = nj * nranks; c->comm.j_offset = rank * nj;
     c->g = lv[0];
     Carver cv{c->ws, 0, need};

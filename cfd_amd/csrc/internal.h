@@ -164,6 +164,7 @@ struct Ctx {
     double mom_tol = 1e-8, p_tol = 1e-8, turb_tol = 1e-8;
     int mom_maxiter = 200, p_maxiter = 200, turb_maxiter = 200, freeze_pressure = 1;
     int mg_pre = 2, mg_post = 2, mg_coarse_sweeps = 40, mg_min = 4;
+    double mg_gamma = 1.0;       // scaling of the prolongated coarse correction
     double mg_omega = 0.8, mg_omega2 = 0.0;   // omega2 <= 0: same damping on every sweep
     int warm_start = 1;          // Krylov initial guess = previous field (reference: zero)
     int use_chebyshev = 1;       // Chebyshev semi-iteration for time-step dominated transport systems
@@ -232,7 +233,8 @@ int launch_metrics_from_nodes(Ctx *c, const double *xn, const double *yn, int no
 int launch_metrics_from_rect(Ctx *c, const double *x1, const double *y1);
 
 // comm.hip -- no-ops on a single rank
-int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b = nullptr, double *d = nullptr);
+int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b = nullptr, double *d = nullptr,
+                  double *e = nullptr);
 int all_reduce(Ctx *c, double *dev, int n, int op);    // op: 0 sum, 1 min
 int all_gather_rows(Ctx *c, const double *src, double *dst, size_t elems_each);
 inline double global_cells(const Ctx *c) {

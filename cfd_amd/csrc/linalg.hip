@@ -508,10 +508,10 @@ __global__ void k_mg_restrict(OpDev op, const double *b, const double *x, Geo gc
     }
 }
 // x += P e (piecewise constant)
-__global__ void k_mg_prolong(Geo g, Tiling T, Geo gc, int fi, int fj, const double *e, double *x) {
+__global__ void k_mg_prolong(Geo g, Tiling T, Geo gc, int fi, int fj, const double *e, double gamma, double *x) {
     TILE_LOOP(g, T) {
         const size_t c = g.cell(i, j);
-        x[c] += e[gc.cell(i / fi, j / fj)];
+        x[c] += gamma * e[gc.cell(i / fi, j / fj)];
     }
 }
 // coarse face conductances: parallel sum across the face, series (1/f) along its normal
@@ -731,7 +731,8 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
 
 template <bool FINE>
 __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const double *b, const double *x, Geo gc,
-                                               const double *e, double omega, double omega2, double *xn, double *partials) {
+                                               const double *e, double gamma, double omega, double omega2, double *xn,
+                                               double *partials) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const doub
             valid = cvalid && mr >= 0;
             const int js = (mr >= 0 ? mr : 2) - 2;     // -2, -1 / nj, nj+1 are halo rows at a slab cut
             const size_t c = (size_t)(js + 2) * P + colo;
-            const double xv = x[c] + e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
+            const double xv = x[c] + gamma * e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
             x0 = valid ? xv : 0.0;
             return load_rowc(op, b, c, mr < g.nj + 3 ? P : 0);
         };
@@ -1044,8 +1045,9 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             o1.p[q] = set[m & 1][0][q]; o2.p[q] = set[m & 1][1][q];
         }
         if (m > 1 && c->comm.nranks > 1) {
-            CFD_TRY(halo_exchange(c, g, 2, cur_k[0], NB == 2 ? cur_k[NB - 1] : nullptr));
-            CFD_TRY(halo_exchange(c, g, 1, cur_m[0], NB == 2 ? cur_m[NB - 1] : nullptr));
+            // x_k needs two rows, x_{k-1} one: a single message set of depth 2 for all of them
+            if (NB == 2) CFD_TRY(halo_exchange(c, g, 2, cur_k[0], cur_k[NB - 1], cur_m[0], cur_m[NB - 1]));
+            else CFD_TRY(halo_exchange(c, g, 2, cur_k[0], cur_m[0]));
         }
         double c1a, c2a, c1b, c2b;
         cc.next(c1a, c2a);
@@ -1405,12 +1407,12 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             CFD_TRY(halo_exchange(c, L.g, 2, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
-                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om, om2,
+                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);
                 c->probe_end(7);
                 *dot_blocks = (int)grid.x;
             } else {
-                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, om, om2,
+                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);
             }
             std::swap(cur[l], oth[l]);
@@ -1420,7 +1422,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         const Tiling T = tiling(L.g);
         int fi, fj;
         factors(L.g, cg, fi, fj);
-        hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, cg, fi, fj, e, cur[l]);
+        hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, cg, fi, fj, e, c->mg_gamma, cur[l]);
         for (int s = 0; s < post; ++s) {
             CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
             hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], (s & 1) ? om2 : om, oth[l]);
@@ -1651,7 +1653,7 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                     if (c->levels.size() > 1 && level_fusable(c, c->levels[0].g, coarse_view(c, 1))) {
                         const MarchGeo mgeo = march_geo(g);
                         hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->kry[1],
-                                           c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_omega, c->mg_omega, c->kry[5], c->partials);
+                                           c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_gamma, c->mg_omega, c->mg_omega, c->kry[5], c->partials);
                     } else {
                         hipLaunchKernelGGL(k_mg_jacobi, grid, blk, 0, st, op, T, c->kry[1], c->kry[4], c->mg_omega, c->kry[5]);
                     }

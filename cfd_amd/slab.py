@@ -54,6 +54,7 @@ class SlabComm:
         # gloo moves host memory only: stage device views through the host
         self.staged = ws.is_cuda and backend != "nccl"
         self.error = None
+        self._plans = {}
         self.n_halo = self.n_reduce = self.n_gather = 0
         self._halo_c = _lib.HALO_FN(self._halo_cb)
         self._reduce_c = _lib.ALLREDUCE_FN(self._reduce_cb)
@@ -76,31 +77,48 @@ class SlabComm:
         return contextlib.nullcontext()
 
     # ------------------------------------------------------------------ collectives
-    def halo(self, plane_ptrs, pitch, nj_local, depth):
-        """Rows [nj-d, nj) -> rows [-d, 0) of rank+1 ; rows [0, d) -> rows [nj, nj+d) of rank-1.
-        Plane row r holds j = r - 2 (two ghost rows below the interior)."""
+    def _halo_plan(self, plane_ptrs, pitch, nj_local, depth):
+        """(send tensors, recv tensors, P2P ops) of one exchange; cached, the library repeats few patterns."""
+        key = (tuple(plane_ptrs), pitch, nj_local, depth)
+        plan = self._plans.get(key)
+        if plan is not None:
+            return plan
         dist = self.dist
         n = depth * pitch
         up, dn = self.rank + 1, self.rank - 1
         sends, recvs = [], []   # (tensor, peer)
         for p in plane_ptrs:
-            row = lambda r: self.view(p + 8 * r * pitch, n)
+            def row(r, p=p):
+                return self.view(p + 8 * r * pitch, n)
             if up < self.nranks:
                 sends.append((row(2 + nj_local - depth), up))
                 recvs.append((row(2 + nj_local), up))
             if dn >= 0:
                 sends.append((row(2), dn))
                 recvs.append((row(2 - depth), dn))
+        ops = None
+        if not self.staged:
+            ops = [dist.P2POp(dist.isend, t, self._peer(peer), self.group) for t, peer in sends]
+            ops += [dist.P2POp(dist.irecv, t, self._peer(peer), self.group) for t, peer in recvs]
+        plan = (sends, recvs, ops)
+        if len(self._plans) < 4096:
+            self._plans[key] = plan
+        return plan
+
+    def halo(self, plane_ptrs, pitch, nj_local, depth):
+        """Rows [nj-d, nj) -> rows [-d, 0) of rank+1 ; rows [0, d) -> rows [nj, nj+d) of rank-1.
+        Plane row r holds j = r - 2 (two ghost rows below the interior)."""
+        dist = self.dist
+        sends, recvs, ops = self._halo_plan(plane_ptrs, pitch, nj_local, depth)
         if not sends:
             return
         with self._ctx():
             if self.staged:
+                n = depth * pitch
                 s_host = [(t.cpu(), peer) for t, peer in sends]
                 r_host = [(self.torch.empty(n, dtype=self.torch.float64), peer) for _, peer in recvs]
-            else:
-                s_host, r_host = sends, recvs
-            ops = [dist.P2POp(dist.isend, t, self._peer(peer), self.group) for t, peer in s_host]
-            ops += [dist.P2POp(dist.irecv, t, self._peer(peer), self.group) for t, peer in r_host]
+                ops = [dist.P2POp(dist.isend, t, self._peer(peer), self.group) for t, peer in s_host]
+                ops += [dist.P2POp(dist.irecv, t, self._peer(peer), self.group) for t, peer in r_host]
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
             if self.staged:
@@ -161,8 +179,14 @@ class SlabComm:
         check(lib.cfd_set_comm(handle, self._halo_c, self._reduce_c, self._gather_c, None))
 
 
-def slab_device(ni, nj_global, device=0, group=None):
-    """Device context of this rank's slab; torch.distributed must be initialised when world > 1."""
+DEFAULT_MIN_SLAB_ROWS = 512
+
+
+def slab_device(ni, nj_global, device=0, group=None, min_slab_rows=None):
+    """Device context of this rank's slab; torch.distributed must be initialised when world > 1.
+    min_slab_rows: multigrid levels stay slab-distributed while a slab keeps at least this many rows
+    (3 halo exchanges per level and V-cycle); coarser levels are replicated on every rank."""
+    min_slab_rows = max(16, int(DEFAULT_MIN_SLAB_ROWS if min_slab_rows is None else min_slab_rows))
     import torch
     import torch.distributed as dist
     from .device import Device
@@ -174,7 +198,7 @@ def slab_device(ni, nj_global, device=0, group=None):
         dev.j_offset, dev.nj_global, dev.rank, dev.nranks = 0, int(nj_global), 0, 1
         return dev
     lib = _lib.load()
-    need = lib.cfd_workspace_bytes_slab(int(ni), int(nj_local), int(world))
+    need = lib.cfd_workspace_bytes_slab(int(ni), int(nj_local), int(world), min_slab_rows)
     if need == 0:
         raise _lib.HipError("cfd_workspace_bytes_slab rejected the slab shape")
     torch.cuda.set_device(device)
@@ -188,7 +212,7 @@ def slab_device(ni, nj_global, device=0, group=None):
     dev._h = C.c_void_p()
     dev.turbulent = False
     check(lib.cfd_create_slab(C.byref(dev._h), dev.ni, dev.nj, int(device), C.c_void_p(ws.data_ptr()), int(need),
-                              int(rank), int(world)))
+                              int(rank), int(world), min_slab_rows))
     check(lib.cfd_set_stream(dev._h, C.c_void_p(stream.cuda_stream)))
     comm = SlabComm(ws, rank, world, group=group, stream=stream)
     comm.install(lib, dev._h)

@@ -439,7 +439,8 @@ def run_case(config):
     # and owns one j-slab; rank 0 writes the logs and states, every rank returns the whole fields
     if _distributed_world() > 1:
         from .slab import slab_device
-        dev = slab_device(count_i, count_j, default_device_ordinal(solver_cfg))
+        dev = slab_device(count_i, count_j, default_device_ordinal(solver_cfg),
+                          min_slab_rows=solver_cfg.get("slab", {}).get("min_rows"))
     else:
         dev = Device(count_i, count_j, default_device_ordinal(solver_cfg))
     root = dev.rank == 0

@@ -107,9 +107,11 @@ typedef int (*cfd_halo_fn)(void *user, int nplanes, double *const *planes, int p
 typedef int (*cfd_allreduce_fn)(void *user, double *dev, int n, int op);
 /* dst[rank * elems .. (rank+1) * elems) = src of that rank, for all ranks (device pointers)     */
 typedef int (*cfd_allgather_fn)(void *user, const double *src, double *dst, size_t elems);
-size_t cfd_workspace_bytes_slab(int ni, int nj_local, int nranks);
+/* min_slab_rows (>= 16): a multigrid level stays slab-distributed while each slab keeps at least this
+ * many rows; the next level is replicated.  Must be the same on every rank.                        */
+size_t cfd_workspace_bytes_slab(int ni, int nj_local, int nranks, int min_slab_rows);
 int cfd_create_slab(cfd_ctx **out, int ni, int nj_local, int device, void *workspace, size_t workspace_bytes,
-                    int rank, int nranks);
+                    int rank, int nranks, int min_slab_rows);
 int cfd_set_comm(cfd_ctx *ctx, cfd_halo_fn halo, cfd_allreduce_fn allreduce, cfd_allgather_fn allgather, void *user);
 /* refresh the cut ghost rows of a field plane (after cfd_upload_field on every rank)            */
 int cfd_exchange_field(cfd_ctx *ctx, int field_id);

@@ -44,6 +44,8 @@ def build_case(name, work):
     if fixup is not None:
         fixup(cfg, mesh)
     cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+    # small test meshes: keep the multigrid levels slab-distributed as long as possible
+    cfg["solver"]["slab"] = {"min_rows": int(os.environ.get("SLAB_MIN_ROWS", "16"))}
     if os.environ.get("SLAB_UNFUSED"):
         cfg["solver"]["multigrid"] = {"fused": False}
     return cfg

@@ -23,10 +23,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(case, world, out_dir):
+def _run(case, world, out_dir, min_rows=16):
     out_dir.mkdir(parents=True, exist_ok=True)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", SLAB_MIN_ROWS=str(min_rows))
     procs = []
     for rank in range(world):
         e = dict(env, RANK=str(rank), LOCAL_RANK="0")
@@ -52,13 +52,15 @@ def _run(case, world, out_dir):
     return np.load(out_dir / "result.npz")
 
 
-@pytest.mark.parametrize("case,world", [
-    ("channel_komega_48x64", 2), ("channel_komega_48x64", 4), ("channel_lam_64x128", 2),
-    ("inlet_outlet_40x32", 2), ("couette_piso_24x32", 2), ("half_cylinder_komega_24x32", 2),
+@pytest.mark.parametrize("case,world,min_rows", [
+    ("channel_komega_48x64", 2, 16), ("channel_komega_48x64", 4, 16), ("channel_lam_64x128", 2, 16),
+    ("channel_lam_64x128", 2, 512),      # production threshold: only the finest level is slab-distributed
+    ("inlet_outlet_40x32", 2, 16), ("couette_piso_24x32", 2, 16), ("half_cylinder_komega_24x32", 2, 16),
 ])
-def test_slab_run_matches_single_rank(case, world, tmp_path):
+def test_slab_run_matches_single_rank(case, world, min_rows, tmp_path):
+    """min_rows = 16 keeps the multigrid levels slab-distributed as deep as the mesh allows."""
     one = _run(case, 1, tmp_path / "w1")
-    many = _run(case, world, tmp_path / f"w{world}")
+    many = _run(case, world, tmp_path / f"w{world}", min_rows)
     assert int(one["step"]) == int(many["step"])
     assert abs(float(one["time"]) - float(many["time"])) <= 1e-12 * max(1.0, abs(float(one["time"])))
     unorm = max(1.0, np.linalg.norm(one["field_u"].ravel()))

@@ -23,7 +23,7 @@ def main():
     fields = S.initialize_fields(mesh, cfg["initial"])
     ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
     fields.setdefault("nu_t", np.zeros((ni + 2, nj + 2)))
-    dev = slab_device(ni, nj, 0)
+    dev = slab_device(ni, nj, 0, min_slab_rows=16)
     dev.upload_mesh(mesh)
     S.configure_device(dev, cfg, BoundaryGeometry.from_nodes(mesh["node"]), cfg["physics"]["nu"], ctl.turb_on)
     dev.upload_fields(fields)

@@ -27,7 +27,7 @@ def main():
     r = rng.standard_normal((ni, nj))
     out = {}
     for fused in (0, 1):
-        dev = slab_device(ni, nj, 0)
+        dev = slab_device(ni, nj, 0, min_slab_rows=16)
         dev.upload_mesh(mesh)
         cfg["solver"]["multigrid"] = {"fused": bool(fused)}
         S.configure_device(dev, cfg, BoundaryGeometry.from_nodes(mesh["node"]), cfg["physics"]["nu"], ctl.turb_on)
