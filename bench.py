@@ -9,11 +9,11 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
     torchrun ... bench.py --gpus N ...                        (one rank per GPU)
 
 The JSON line also carries
-  roofline     : the kernel with the largest share of device time, k_cheb2<2> (two Chebyshev
-                 iterations of the u and v momentum systems per launch), timed live with HIP-event
-                 pairs around every launch inside the timed steps; achieved = 104 B/cell * Ni*Nj /
-                 avg duration (x_k, x_{k-1}, b of u and v + D, c_i, c_j read; x_{k+1}, x_{k+2} of u
-                 and v written).  --probe 7 / 1 / 0 select the multigrid up / down kernels / the
+  roofline     : the kernel with the largest share of device time, k_chebk<2,4> (four Chebyshev
+                 iterations of the u and v momentum systems per launch; two on j-slab runs), timed
+                 live with HIP-event pairs around every launch inside the timed steps; achieved =
+                 104 B/cell * Ni*Nj / avg duration (x_k, x_{k-1}, b of u and v + D, c_i, c_j read; the
+                 last two iterates of u and v written).  --probe 7 / 1 / 0 select the multigrid up / down kernels / the
                  pressure SpMV instead.  traffic = HBM bytes per launch from the committed PMC passes
                  of this command (profiles/r1d_pmc8192_bytes_per_cell.csv), quoted only at the
                  default size they were measured on.
@@ -185,7 +185,7 @@ def main():
         kernel_names = {0: "pressure SpMV (k_cg_q)",
                         1: "MG pre-smoother, finest level: 2 fused Jacobi sweeps + residual + restrict (k_mg_down<true>)",
                         2: "momentum RHS (k_momentum_rhs)", 3: "batched momentum operator (k_bi_apply<2>)",
-                        8: "momentum Chebyshev, two fused iterations of u and v per launch (k_cheb2<2>)",
+                        8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>; k_cheb2<2> on j-slab runs)",
                         7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
         bytes_per_cell = {0: 40, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]
         achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0

@@ -527,6 +527,7 @@ int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double
     if (!(rho_max > 0.0 && rho_max < 1.0) || max_iters < 1) { set_error("cfd_set_transport_solver: bad parameters"); return CFD_E_ARG; }
     c->warm_start = warm_start ? 1 : 0; c->use_chebyshev = chebyshev ? 1 : 0;
     c->cheb_rho_max = rho_max; c->cheb_max_iters = max_iters;
+    if (const char *e = getenv("CFD_CHEB_STAGES")) c->cheb_stages = atoi(e);      // tuning / A-B measurements
     return CFD_OK;
 }
 

@@ -169,6 +169,7 @@ struct Ctx {
     int warm_start = 1;          // Krylov initial guess = previous field (reference: zero)
     int use_chebyshev = 1;       // Chebyshev semi-iteration for time-step dominated transport systems
     double cheb_rho_max = 0.95;  // ... i.e. Jacobi row-sum bound below this
+    int cheb_stages = 4;         // Chebyshev iterations fused per launch on single-slab contexts (2 or 4)
     int cheb_max_iters = 80;     // ... and predicted iteration count below this; else BiCGStab
     int stats_last_solver = 0;   // 1 = the last transport solve was Chebyshev
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable

@@ -966,6 +966,117 @@ __global__ __launch_bounds__(256) void k_cheb2(OpDev op, MarchGeo mg, double c1a
             (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
 }
 
+// K Chebyshev iterations per pass (same marching scheme, K halo lanes / rows on each side): x_k,
+// x_{k-1}, b, D, c_i, c_j are still read once and x_{k+K-1}, x_{k+K} written, so the 104 B buy K
+// iterations.  Stage s (1..K) produces iterate k+s on row j-s while row j is being loaded; |r_k|^2 and
+// |r_{k+K-1}|^2 (the residuals of the two iterates that exist in memory afterwards) are the partial
+// sums [q] and [NB + q], |b|^2 is [2 NB + q] on the first launch.  Single-slab contexts only: a slab
+// cut carries two halo rows, not K.
+template <int K>
+struct ChebStages {
+    double c1[K], c2[K];
+};
+template <int NB, int K>
+__global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages<K> cf, int first, CVecs<NB> b,
+                                               CVecs<NB> xk, CVecs<NB> xm, Vecs<NB> xlo, Vecs<NB> xhi, double *partials) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    constexpr int W = 64 - 2 * K;
+    double acc[3 * NB];
+#pragma unroll
+    for (int q = 0; q < 3 * NB; ++q) acc[q] = 0.0;
+    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+        const int iraw = strip * W - K + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        // X[s][0..2]: iterate k+s on rows (j-s-2, j-s-1, j-s); RA[s], B[s], V[s], CELL[s]: row j-s
+        double X[K + 1][3][NB], B[K + 1][NB];
+        RowA RA[K + 1];
+        bool V[K + 1];
+        size_t CELL[K + 1];
+#pragma unroll
+        for (int s2 = 0; s2 <= K; ++s2) {
+            V[s2] = false; CELL[s2] = 2 * P + colo;
+            RA[s2] = RowA{1.0, 1.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < NB; ++q) { X[s2][0][q] = 0.0; X[s2][1][q] = 0.0; X[s2][2][q] = 0.0; B[s2][q] = 0.0; }
+        }
+        for (int j = j0 - K; j < j1 + K; ++j) {
+            // newest row: operator row, x_k, b
+            {
+                const int mr = mem_row(j, g, op.per_j);
+                V[0] = cvalid && mr >= 0;
+                const size_t c = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+                CELL[0] = c;
+                RA[0].d = op.D[c]; RA[0].cw = op.ci[c]; RA[0].ce = op.ci[c + 1]; RA[0].cs = op.cj[c];
+                RA[0].cn = op.cj[c + (mr < g.nj + 3 ? P : 0)];
+                RA[0].inv = fast_rcp(RA[0].d);
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    X[0][2][q] = V[0] ? xk.p[q][c] : 0.0;
+                    B[0][q] = b.p[q][c];
+                }
+            }
+#pragma unroll
+            for (int s2 = 1; s2 <= K; ++s2) {
+                const int row = j - s2;
+                const bool inr = row >= j0 && row < j1 && out;
+                const RowA ra = RA[s2];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const double xc = X[s2 - 1][1][q];
+                    const double xl = lane_left(xc), xr = lane_right(xc);
+                    const double r = B[s2][q] - (ra.d * xc - (ra.cw * xl + ra.ce * xr + ra.cs * X[s2 - 1][0][q] + ra.cn * X[s2 - 1][2][q]));
+                    double step = cf.c2[s2 - 1] * (r * ra.inv);
+                    if (s2 == 1) {
+                        if (!first) step += cf.c1[0] * (xc - xm.p[q][CELL[1]]);
+                    } else {
+                        step += cf.c1[s2 - 1] * (xc - X[s2 - 2][0][q]);
+                    }
+                    const double xn = V[s2] ? xc + step : 0.0;
+                    X[s2][2][q] = xn;
+                    if (inr) {
+                        if (s2 == 1) {
+                            acc[q] += r * r;
+                            if (first) acc[2 * NB + q] += B[1][q] * B[1][q];
+                        }
+                        if (s2 == K) acc[NB + q] += r * r;
+                        if (s2 == K - 1) xlo.p[q][CELL[s2]] = xn;
+                        if (s2 == K) xhi.p[q][CELL[s2]] = xn;
+                    }
+                }
+            }
+            // slide every window one row down
+#pragma unroll
+            for (int s2 = K; s2 >= 1; --s2) {
+                RA[s2] = RA[s2 - 1]; V[s2] = V[s2 - 1]; CELL[s2] = CELL[s2 - 1];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) B[s2][q] = B[s2 - 1][q];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 <= K; ++s2)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) { X[s2][0][q] = X[s2][1][q]; X[s2][1][q] = X[s2][2][q]; }
+        }
+    }
+    __shared__ double sm[3 * NB][4];
+#pragma unroll
+    for (int q = 0; q < 3 * NB; ++q) {
+        const double w = wsum(acc[q]);
+        if (lane == 0) sm[q][wave] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * NB)
+        partials[(size_t)threadIdx.x * MAX_PARTIALS + blockIdx.x] =
+            (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
 // Chebyshev coefficient stream of Saad's Algorithm 12.1 on [1 - rho, 1 + rho]
 struct ChebCoef {
     double rho, sigma1, rk;
@@ -991,14 +1102,22 @@ struct ChebCoef {
     }
 };
 
-template <int NB>
+template <int NB, int K>
 static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
                            double tol, int maxiter, int *iters, double relres[2], double rms[2], int *used) {
     const Geo g = op.g;
     hipStream_t st = c->stream;
-    const MarchGeo mgeo = march_geo(g);
+    MarchGeo mgeo = march_geo(g);
+    if (K > 2) {
+        // K halo lanes / rows per side: wider strips overlap, longer segments amortise the 2K extra rows
+        mgeo.nstrips = (g.ni + (64 - 2 * K) - 1) / (64 - 2 * K);
+        int Ls = 32;
+        while (Ls > 8 && (long)mgeo.nstrips * ((g.nj + Ls - 1) / Ls) < 8192) Ls /= 2;
+        mgeo.Ls = Ls;
+        mgeo.nsegs = (g.nj + Ls - 1) / Ls;
+    }
     const dim3 grid(march_blocks(mgeo));
-    // iterate buffers: launch m writes x_{2m-1}, x_{2m} into set m & 1 and reads set (m - 1) & 1
+    // iterate buffers: launch m writes x_{Km-1}, x_{Km} into set m & 1 and reads set (m - 1) & 1
     double *set[2][2][NB];
     CVecs<NB> bc;
     for (int q = 0; q < NB; ++q) {
@@ -1049,16 +1168,19 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             if (NB == 2) CFD_TRY(halo_exchange(c, g, 2, cur_k[0], cur_k[NB - 1], cur_m[0], cur_m[NB - 1]));
             else CFD_TRY(halo_exchange(c, g, 2, cur_k[0], cur_m[0]));
         }
-        double c1a, c2a, c1b, c2b;
-        cc.next(c1a, c2a);
-        cc.next(c1b, c2b);
+        ChebStages<K> cf;
+        for (int s2 = 0; s2 < K; ++s2) cc.next(cf.c1[s2], cf.c2[s2]);
         c->probe_begin(8);
-        hipLaunchKernelGGL((k_cheb2<NB>), grid, dim3(256), 0, st, op, mgeo, c1a, c2a, c1b, c2b, m == 1 ? 1 : 0, bc, xk, xm,
-                           o1, o2, c->partials);
+        if (K == 2)
+            hipLaunchKernelGGL((k_cheb2<NB>), grid, dim3(256), 0, st, op, mgeo, cf.c1[0], cf.c2[0], cf.c1[1], cf.c2[1],
+                               m == 1 ? 1 : 0, bc, xk, xm, o1, o2, c->partials);
+        else
+            hipLaunchKernelGGL((k_chebk<NB, K>), grid, dim3(256), 0, st, op, mgeo, cf, m == 1 ? 1 : 0, bc, xk, xm, o1, o2,
+                               c->partials);
         c->probe_end(8);
         CFD_HIP(hipGetLastError());
-        const int k0 = 2 * m - 2;                  // this launch measured |r_k0| and |r_{k0+1}|
-        if (m == 1 || k0 + 1 >= kpred || k0 + 1 >= klimit) {
+        const int k0 = K * (m - 1);                // this launch measured |r_k0| and |r_{k0+K-1}|
+        if (m == 1 || k0 + K - 1 >= kpred || k0 + K - 1 >= klimit) {
             const int nq = m == 1 ? 3 * NB : 2 * NB;
             CFD_TRY(sum_finish(c, c->partials, (int)grid.x, nq, c->scal));
             double got[6];
@@ -1077,14 +1199,14 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                 klimit = std::min(maxiter, kpred + 8 + kpred / 2);
             }
             if (done(got)) return finish(k0, got, cur_k);
-            if (done(got + NB)) return finish(k0 + 1, got + NB, set[m & 1][0]);
-            if (k0 + 1 >= klimit) {
+            if (done(got + NB)) return finish(k0 + K - 1, got + NB, set[m & 1][0]);
+            if (k0 + K - 1 >= klimit) {
                 // bound not met (spectrum outside the interval): hand the newest iterate to BiCGStab
                 for (int q = 0; q < NB; ++q)
                     if (set[m & 1][1][q] != x[q])
                         CFD_HIP(hipMemcpyAsync(x[q], set[m & 1][1][q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
                 *used = 2;
-                *iters = k0 + 2;
+                *iters = k0 + K;
                 return CFD_OK;
             }
         }
@@ -1109,7 +1231,10 @@ static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double 
         CFD_TRY(read_scalars(c, 12, 1, c->h_scal + 12));      // h_scal[12] = -rho
         const double rho_f = -c->h_scal[12];
         if (!(rho_f >= 0.0) || rho_f > c->cheb_rho_max) return CFD_OK;
-        return chebyshev_fused<NB>(c, op, b, x, x0, tol, maxiter, iters, relres, rms, used);
+        // four iterations per launch where no slab cut limits the halo depth to two rows
+        if (c->comm.nranks == 1 && c->cheb_stages >= 4 && g.ni >= 64 && g.nj >= 64)
+            return chebyshev_fused<NB, 4>(c, op, b, x, x0, tol, maxiter, iters, relres, rms, used);
+        return chebyshev_fused<NB, 2>(c, op, b, x, x0, tol, maxiter, iters, relres, rms, used);
     }
     // first pass: r_0, |b|^2, x_1 = x_0 + r_0 / D  (theta = 1)
     CVecs<NB> bc, xk, xm;
