@@ -1627,6 +1627,80 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
     block_sums<1>(acc, partials);
 }
 
+// Fused PCG direction step (marching, one halo lane / row):  p' = z + beta p ;  q = A p' ;  (p', q) ;
+// and the solution update of the PREVIOUS iteration, x += alpha_prev p, which reads the same p.
+// 72 B/cell (z, p, x, D, c_i, c_j read; p', q, x written) instead of 24 + 40 for k_cg_p + k_cg_q and
+// 16 of the 48 of k_cg_xr, whose remainder is k_cg_r below.  p' goes to a second plane: neighbouring
+// strips recompute p' on their halo from the old p.
+__global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, const CgScal *s, int gen, int first, const double *z,
+                                               const double *pold, double *pnew, double *q, double *x, double *partials) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    const double beta = first ? 0.0 : safe_div(s->rz[gen], s->rz[gen ^ 1]);
+    const double alpha_prev = first ? 0.0 : safe_div(s->rz[gen ^ 1], s->pq);
+    double dot = 0.0;
+    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+        const int iraw = strip * 62 - 1 + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const bool out = lane >= 1 && lane < 63 && iraw < g.ni;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        double pa = 0.0, pb = 0.0, pc, po_b = 0.0, po_c;
+        double d_b = 1.0, cw_b = 0.0, ce_b = 0.0, cs_b = 0.0, cn_b = 0.0;
+        size_t cell_b = 2 * P + colo;
+        for (int j = j0 - 1; j <= j1; ++j) {
+            const int mr = mem_row(j, g, op.per_j);
+            const bool valid = cvalid && mr >= 0;
+            const size_t cc = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+            po_c = first ? 0.0 : pold[cc];
+            pc = valid ? z[cc] + beta * po_c : 0.0;
+            const double d_c = op.D[cc], cw_c = op.ci[cc], ce_c = op.ci[cc + 1], cs_c = op.cj[cc],
+                         cn_c = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+            // row j-1
+            const double pl = lane_left(pb), pr = lane_right(pb);
+            if (j - 1 >= j0 && out) {
+                const double qv = d_b * pb - (cw_b * pl + ce_b * pr + cs_b * pa + cn_b * pc);
+                pnew[cell_b] = pb;
+                q[cell_b] = qv;
+                if (!first) x[cell_b] = x[cell_b] + alpha_prev * po_b;
+                dot += pb * qv;
+            }
+            pa = pb; pb = pc; po_b = po_c;
+            d_b = d_c; cw_b = cw_c; ce_b = ce_c; cs_b = cs_c; cn_b = cn_c;
+            cell_b = cc;
+        }
+    }
+    __shared__ double sm[4];
+    const double w = wsum(dot);
+    if (lane == 0) sm[wave] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// r -= alpha q ; partial = (r, r)
+__global__ void k_cg_r(Geo g, Tiling T, const CgScal *s, int gen, const double *q, double *r, double *partials) {
+    const double alpha = safe_div(s->rz[gen], s->pq);
+    double acc[1] = {0.0};
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+        const double rn = r[c] - alpha * q[c];
+        r[c] = rn;
+        acc[0] += rn * rn;
+    }
+    block_sums<1>(acc, partials);
+}
+// x += alpha p  (the update the fused direction step still owes after the last iteration)
+__global__ void k_cg_xlast(Geo g, Tiling T, const CgScal *s, int gen, const double *p, double *x) {
+    const double alpha = safe_div(s->rz[gen], s->pq);
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+        x[c] = x[c] + alpha * p[c];
+    }
+}
+
 static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres) {
     const Level &L0 = c->levels[0];
     const OpDev op = level_op(c, L0);
@@ -1636,6 +1710,12 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     hipStream_t st = c->stream;
     CgScal *S = reinterpret_cast<CgScal *>(c->scal + CG_OFF);
     double *r = c->kry[1], *p = c->kry[2], *q = c->kry[3], *za = c->kry[4], *zb = c->kry[5];
+    // fused direction step: marching kernel, p ping-pongs between two planes
+    const bool fused = c->mg_fused && g.ni >= 16 && g.nj >= 16;
+    double *pbuf[2] = {c->kry[2], c->kry[6]};
+    MarchGeo mgeo = march_geo(g);
+    mgeo.nstrips = (g.ni + 61) / 62;
+    const dim3 mgrid(march_blocks(mgeo));
     CFD_HIP(hipMemsetAsync(S, 0, sizeof(CgScal), st));
     hipLaunchKernelGGL(k_cg_init, grid, blk, 0, st, g, T, b, r, x, c->partials);
     CFD_HIP(hipGetLastError());
@@ -1661,20 +1741,36 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             CFD_HIP(hipGetLastError());
             CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rz[gen])));
         }
-        hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);
-        CFD_TRY(halo_exchange(c, g, 1, p));
-        c->probe_begin(0);
-        hipLaunchKernelGGL(k_cg_q, grid, blk, 0, st, op, T, p, q, c->partials);
-        c->probe_end(0);
-        CFD_HIP(hipGetLastError());
-        CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(pq)));
-        hipLaunchKernelGGL(k_cg_xr, grid, blk, 0, st, g, T, S, gen, p, q, x, r, c->partials);
+        if (fused) {
+            double *pold = pbuf[gen ^ 1];
+            p = pbuf[gen];
+            CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
+            c->probe_begin(0);
+            hipLaunchKernelGGL(k_cg_pq, mgrid, dim3(256), 0, st, op, mgeo, S, gen, it == 0, z, pold, p, q, x, c->partials);
+            c->probe_end(0);
+            CFD_HIP(hipGetLastError());
+            CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));
+            hipLaunchKernelGGL(k_cg_r, grid, blk, 0, st, g, T, S, gen, q, r, c->partials);
+        } else {
+            hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);
+            CFD_TRY(halo_exchange(c, g, 1, p));
+            c->probe_begin(0);
+            hipLaunchKernelGGL(k_cg_q, grid, blk, 0, st, op, T, p, q, c->partials);
+            c->probe_end(0);
+            CFD_HIP(hipGetLastError());
+            CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(pq)));
+            hipLaunchKernelGGL(k_cg_xr, grid, blk, 0, st, g, T, S, gen, p, q, x, r, c->partials);
+        }
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rr)));
         ++it;
         CFD_TRY(read_scalars(c, CG_OFF_OF(rr), 1, &rr));
         if (!(rr == rr)) { set_error("PCG: non-finite residual at iteration %d", it); return CFD_E_NUMERIC; }
         if (sqrt(rr) <= tol * sqrt(bb)) break;
+    }
+    if (fused && it > 0) {
+        hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, p, x);
+        CFD_HIP(hipGetLastError());
     }
     *iters = it;
     *relres = sqrt(rr / bb);
