@@ -9,14 +9,14 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
     torchrun ... bench.py --gpus N ...                        (one rank per GPU)
 
 The JSON line also carries
-  roofline     : the kernel with the largest share of device time, k_chebk<2,4> (four Chebyshev
-                 iterations of the u and v momentum systems per launch; two on j-slab runs), timed
-                 live with HIP-event pairs around every launch inside the timed steps; achieved =
-                 104 B/cell * Ni*Nj / avg duration (x_k, x_{k-1}, b of u and v + D, c_i, c_j read; the
-                 last two iterates of u and v written).  --probe 7 / 1 / 0 select the multigrid up / down kernels / the
-                 pressure SpMV instead.  traffic = HBM bytes per launch from the committed PMC passes
-                 of this command (profiles/r1d_pmc8192_bytes_per_cell.csv), quoted only at the
-                 default size they were measured on.
+  roofline     : the kernel with the largest share of device time, k_cg_pq (fused PCG direction
+                 step of the pressure solve: p' = z + beta p, q = A p', (p', q), deferred x update),
+                 timed live with HIP-event pairs around every launch inside the timed steps;
+                 achieved = 72 B/cell * Ni*Nj / avg duration (z, p, x, D, c_i, c_j read; p', q, x
+                 written).  --probe 8 / 7 / 1 select the momentum Chebyshev kernel / the multigrid up /
+                 down kernels instead.  traffic = HBM bytes per launch from the committed PMC passes
+                 of this command (profiles/r1e_pmc8192_bytes_per_cell.csv), quoted only for the
+                 single-GPU default size they were measured on.
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
                  factor-once LU pressure) timed on this host, bounded sample.
 """
@@ -37,8 +37,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 50   # k_mg_up: x, e/4, b, c_i, c_j, D read + x' written, for TWO sweeps + prolongation
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
-# 8192^2 (profiles/r1d_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {8: 108.30, 7: 56.09, 1: 45.92, 0: 43.17, 2: 140.16}
+# 8192^2 (profiles/r1e_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 75.05, 8: 109.71, 7: 56.13, 1: 45.92, 2: 140.25}
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1):
@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--probe", type=int, default=8, help="kernel id for the live roofline probe")
+    ap.add_argument("--probe", type=int, default=0, help="kernel id for the live roofline probe")
     ap.add_argument("--mg-omega", type=float, default=None, help="smoother damping of the even sweeps")
     ap.add_argument("--mg-omega2", type=float, default=None, help="smoother damping of the odd sweeps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -182,17 +182,18 @@ def main():
 
     out = None
     if rank == 0:
-        kernel_names = {0: "pressure SpMV (k_cg_q)",
+        kernel_names = {0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq)",
                         1: "MG pre-smoother, finest level: 2 fused Jacobi sweeps + residual + restrict (k_mg_down<true>)",
                         2: "momentum RHS (k_momentum_rhs)", 3: "batched momentum operator (k_bi_apply<2>)",
                         8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>; k_cheb2<2> on j-slab runs)",
                         7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
-        bytes_per_cell = {0: 40, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]
+        bytes_per_cell = {0: 72, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]
         achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
                     "traffic": (PMC_TRAFFIC_BYTES_PER_CELL_8192[args.probe] * n * n
-                                if n == 8192 and not args.turbulent and args.probe in PMC_TRAFFIC_BYTES_PER_CELL_8192 else None),
+                                if n == 8192 and world == 1 and not args.turbulent and args.probe in PMC_TRAFFIC_BYTES_PER_CELL_8192
+                                else None),
                     "traffic_unit": "bytes per launch (PMC, committed profile)",
                     "kernel": kernel_names.get(args.probe, str(args.probe)),
                     "avg_us": probe_us, "launches_timed": n_probe, "bytes_per_cell": bytes_per_cell}
