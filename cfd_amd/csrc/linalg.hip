@@ -1007,21 +1007,45 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
 #pragma unroll
             for (int q = 0; q < NB; ++q) { X[s2][0][q] = 0.0; X[s2][1][q] = 0.0; X[s2][2][q] = 0.0; B[s2][q] = 0.0; }
         }
-        for (int j = j0 - K; j < j1 + K; ++j) {
-            // newest row: operator row, x_k, b
-            {
-                const int mr = mem_row(j, g, op.per_j);
-                V[0] = cvalid && mr >= 0;
-                const size_t c = (size_t)(mr >= 0 ? mr : 2) * P + colo;
-                CELL[0] = c;
-                RA[0].d = op.D[c]; RA[0].cw = op.ci[c]; RA[0].ce = op.ci[c + 1]; RA[0].cs = op.cj[c];
-                RA[0].cn = op.cj[c + (mr < g.nj + 3 ? P : 0)];
-                RA[0].inv = fast_rcp(RA[0].d);
+        // software pipeline: the loads of row j + 1 are issued before the K stages of row j run, so a
+        // wave always has one row of loads in flight (at 2 waves per SIMD nothing else hides the latency)
+        struct RowIn {
+            double d, cw, ce, cs, cn, x[NB], b[NB], xm[NB];
+            bool valid;
+            size_t cell;
+        };
+        auto fetch = [&](int j, RowIn &R) {
+            const int mr = mem_row(j, g, op.per_j);
+            R.valid = cvalid && mr >= 0;
+            const size_t c = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+            R.cell = c;
+            R.d = op.D[c]; R.cw = op.ci[c]; R.ce = op.ci[c + 1]; R.cs = op.cj[c];
+            R.cn = op.cj[c + (mr < g.nj + 3 ? P : 0)];
 #pragma unroll
-                for (int q = 0; q < NB; ++q) {
-                    X[0][2][q] = V[0] ? xk.p[q][c] : 0.0;
-                    B[0][q] = b.p[q][c];
-                }
+            for (int q = 0; q < NB; ++q) {
+                R.x[q] = xk.p[q][c];
+                R.b[q] = b.p[q][c];
+                R.xm[q] = first ? 0.0 : xm.p[q][c];
+            }
+        };
+        double XM[2][NB];          // x_{k-1} on rows j, j-1
+#pragma unroll
+        for (int q = 0; q < NB; ++q) { XM[0][q] = 0.0; XM[1][q] = 0.0; }
+        RowIn nxt;
+        fetch(j0 - K, nxt);
+        for (int j = j0 - K; j < j1 + K; ++j) {
+            const RowIn cur = nxt;
+            if (j + 1 < j1 + K) fetch(j + 1, nxt);
+            // newest row: operator row, x_k, b
+            V[0] = cur.valid;
+            CELL[0] = cur.cell;
+            RA[0].d = cur.d; RA[0].cw = cur.cw; RA[0].ce = cur.ce; RA[0].cs = cur.cs; RA[0].cn = cur.cn;
+            RA[0].inv = fast_rcp(cur.d);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                X[0][2][q] = cur.valid ? cur.x[q] : 0.0;
+                B[0][q] = cur.b[q];
+                XM[0][q] = cur.xm[q];
             }
 #pragma unroll
             for (int s2 = 1; s2 <= K; ++s2) {
@@ -1035,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
                     const double r = B[s2][q] - (ra.d * xc - (ra.cw * xl + ra.ce * xr + ra.cs * X[s2 - 1][0][q] + ra.cn * X[s2 - 1][2][q]));
                     double step = cf.c2[s2 - 1] * (r * ra.inv);
                     if (s2 == 1) {
-                        if (!first) step += cf.c1[0] * (xc - xm.p[q][CELL[1]]);
+                        if (!first) step += cf.c1[0] * (xc - XM[1][q]);
                     } else {
                         step += cf.c1[s2 - 1] * (xc - X[s2 - 2][0][q]);
                     }
@@ -1059,6 +1083,8 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
 #pragma unroll
                 for (int q = 0; q < NB; ++q) B[s2][q] = B[s2 - 1][q];
             }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) XM[1][q] = XM[0][q];
 #pragma unroll
             for (int s2 = 0; s2 <= K; ++s2)
 #pragma unroll
@@ -1652,24 +1678,45 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, const CgSc
         double pa = 0.0, pb = 0.0, pc, po_b = 0.0, po_c;
         double d_b = 1.0, cw_b = 0.0, ce_b = 0.0, cs_b = 0.0, cn_b = 0.0;
         size_t cell_b = 2 * P + colo;
-        for (int j = j0 - 1; j <= j1; ++j) {
+        // software pipeline: row j + 1 is loaded while row j is processed
+        struct RowIn {
+            double z, po, d, cw, ce, cs, cn, xv;
+            bool valid;
+            size_t cell;
+        };
+        auto fetch = [&](int j, RowIn &R) {
             const int mr = mem_row(j, g, op.per_j);
-            const bool valid = cvalid && mr >= 0;
+            R.valid = cvalid && mr >= 0;
             const size_t cc = (size_t)(mr >= 0 ? mr : 2) * P + colo;
-            po_c = first ? 0.0 : pold[cc];
-            pc = valid ? z[cc] + beta * po_c : 0.0;
-            const double d_c = op.D[cc], cw_c = op.ci[cc], ce_c = op.ci[cc + 1], cs_c = op.cj[cc],
-                         cn_c = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+            R.cell = cc;
+            R.po = first ? 0.0 : pold[cc];
+            R.z = z[cc];
+            R.xv = first ? 0.0 : x[cc];
+            R.d = op.D[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+            R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+        };
+        RowIn nxt;
+        fetch(j0 - 1, nxt);
+        double xv_b = 0.0, xv_c;
+        for (int j = j0 - 1; j <= j1; ++j) {
+            const RowIn cur = nxt;
+            if (j < j1) fetch(j + 1, nxt);
+            const bool valid = cur.valid;
+            const size_t cc = cur.cell;
+            po_c = cur.po;
+            xv_c = cur.xv;
+            pc = valid ? cur.z + beta * po_c : 0.0;
+            const double d_c = cur.d, cw_c = cur.cw, ce_c = cur.ce, cs_c = cur.cs, cn_c = cur.cn;
             // row j-1
             const double pl = lane_left(pb), pr = lane_right(pb);
             if (j - 1 >= j0 && out) {
                 const double qv = d_b * pb - (cw_b * pl + ce_b * pr + cs_b * pa + cn_b * pc);
                 pnew[cell_b] = pb;
                 q[cell_b] = qv;
-                if (!first) x[cell_b] = x[cell_b] + alpha_prev * po_b;
+                if (!first) x[cell_b] = xv_b + alpha_prev * po_b;
                 dot += pb * qv;
             }
-            pa = pb; pb = pc; po_b = po_c;
+            pa = pb; pb = pc; po_b = po_c; xv_b = xv_c;
             d_b = d_c; cw_b = cw_c; ce_b = ce_c; cs_b = cs_c; cn_b = cn_c;
             cell_b = cc;
         }
