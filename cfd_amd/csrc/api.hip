@@ -403,6 +403,7 @@ int cfd_upload_mesh(cfd_ctx *ctx, const double *cell_volume, const double *w_rig
     CFD_TRY(to_device(c, tmp.data(), c->m_lmin, CFD_KIND_CELL));
     c->mesh_set = true;
     c->p_built = false;
+    c->ap_cached = false;
     return CFD_OK;
 }
 
@@ -425,6 +426,7 @@ int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node) {
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
     c->p_built = false;
+    c->ap_cached = false;
     return CFD_OK;
 }
 
@@ -448,6 +450,7 @@ int cfd_mesh_from_rect(cfd_ctx *ctx, const double *x_nodes, const double *y_node
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
     c->p_built = false;
+    c->ap_cached = false;
     return CFD_OK;
 }
 
@@ -467,6 +470,7 @@ int cfd_upload_field(cfd_ctx *ctx, int field_id, const double *host, int kind) {
     double *pl = field_plane(c, field_id);
     if (!pl || !host || kind < 0 || kind > 3) { set_error("cfd_upload_field: bad arguments"); return CFD_E_ARG; }
     CFD_TRY(to_device(c, host, pl, kind));
+    if (field_id == CFD_F_NUT || field_id == CFD_F_AP || field_id == CFD_F_AI || field_id == CFD_F_AJ) c->ap_cached = false;
     // u, v, p exist twice (ping-pong): keep never-written ghosts (corners) identical in both
     if (field_id == CFD_F_U) CFD_TRY(launch_copy_plane(c, pl, c->U1()));
     if (field_id == CFD_F_V) CFD_TRY(launch_copy_plane(c, pl, c->V1()));
@@ -497,6 +501,7 @@ int cfd_download_field(cfd_ctx *ctx, int field_id, double *host, int kind) {
 // ------------------------------------------------------------------ parameters
 int cfd_set_physics(cfd_ctx *ctx, double nu, double dpdx, double dpdy, int rhie_chow, int turbulent) {
     CTX(ctx);
+    c->ap_cached = false;
     c->nu = nu; c->dpdx = dpdx; c->dpdy = dpdy; c->rhie_chow = rhie_chow ? 1 : 0; c->turbulent = turbulent ? 1 : 0;
     return CFD_OK;
 }
@@ -607,6 +612,7 @@ int cfd_set_pressure_bc(cfd_ctx *ctx, const int32_t *mask_imin, const int32_t *m
     c->pin_i = pin_i; c->pin_j = pin_j; c->pin_value = pin_value;
     c->pbc_set = true;
     c->p_built = false;
+    c->ap_cached = false;
     return CFD_OK;
 }
 
@@ -672,10 +678,16 @@ static int flow_bc(Ctx *c, double *u, double *v, double *p) {
 static int do_predictor(Ctx *c, double dt, double res[3]) {
     {
         Phase ph(c, PH_ADV);
-        CFD_TRY(launch_eddy_viscosity(c));
-        CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
-        CFD_TRY(halo_exchange(c, c->g, 1, c->ap));     // Rhie-Chow and d_f read a_P across the cut
-        c->dt_ap = dt;
+        // laminar runs: nu_t = 0 for good, so a_P / a_i / a_j depend on dt only and are rebuilt only when
+        // dt changes (the reference rebuilds the same numbers every inner iteration, solver.py:868-876)
+        if (c->turbulent || !c->ap_cached || c->dt_ap != dt) {
+            CFD_TRY(launch_eddy_viscosity(c));
+            CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+            CFD_TRY(halo_exchange(c, c->g, 1, c->ap));     // Rhie-Chow and d_f read a_P across the cut
+            c->dt_ap = dt;
+            c->ap_cached = !c->turbulent;
+            c->rho_cached = -1.0;
+        }
         c->probe_begin(2);
         CFD_TRY(launch_momentum_rhs(c, dt, c->U(), c->V(), c->P()));
         c->probe_end(2);
@@ -704,13 +716,10 @@ static int do_pressure(Ctx *c, const double *u, const double *v, const double *p
     CFD_TRY(launch_pressure_rhs(c, u, v, p, b));
     int it = 0;
     double rr = 0;
-    CFD_TRY(pressure_solve(c, b, c->kry[10], c->p_tol, c->p_maxiter, &it, &rr));
+    // the solvers write interior cells only: p_corr is solved in place, its ghosts come from the p' BC kernel
+    CFD_TRY(pressure_solve(c, b, c->pcorr, c->p_tol, c->p_maxiter, &it, &rr));
     c->stats.p_iters = it;
     c->stats.p_relres = rr;
-    // interior of p_corr := solution (ghosts are set by the p' BC kernel)
-    CFD_HIP(hipMemcpy2DAsync(c->pcorr + c->g.at(0, 1), c->g.pitch * sizeof(double), c->kry[10] + c->g.at(0, 1),
-                             c->g.pitch * sizeof(double), (size_t)(c->g.ni + 2) * sizeof(double), c->g.nj,
-                             hipMemcpyDeviceToDevice, c->stream));
     return CFD_OK;
 }
 
@@ -786,6 +795,7 @@ int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
     CFD_TRY(ready(c));
     if (!c->turbulent) { set_error("turbulence is disabled"); return CFD_E_STATE; }
     Phase ph(c, PH_TURB);
+    c->ap_cached = false;
     CFD_TRY(launch_turb_bc(c));
     // wall BCs also overwrite interior cells (turbulence.py:304-311): the neighbours' halo rows follow
     CFD_TRY(halo_exchange(c, c->g, 1, c->k, c->omega));
@@ -836,6 +846,7 @@ int cfd_momentum_diagonal(cfd_ctx *ctx, double dt, double nut_coef) {
     CFD_TRY(launch_diffusion_ap(c, dt, nut_coef, c->ai, c->aj, c->ap));
     CFD_TRY(halo_exchange(c, c->g, 1, c->ap));
     c->dt_ap = dt;
+    c->ap_cached = false;
     return CFD_OK;
 }
 

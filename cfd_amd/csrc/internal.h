@@ -175,6 +175,8 @@ struct Ctx {
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
     double k_clip = 1e-10, omega_clip = 1e-10;
     double dt_ap = -1.0;          // dt the a_P plane was built with
+    bool ap_cached = false;       // laminar: a_P / a_i / a_j are current for dt_ap
+    double rho_cached = -1.0;     // Jacobi row-sum bound of the cached momentum operator (< 0: unknown)
 
     cfd_solve_stats stats{};
 

@@ -695,11 +695,34 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
         RowC rc1 = rowc(j0 - 1, v1);
         double x1a = v2 ? omega * rc2.b * rc2.inv : 0.0, x1b = v1 ? omega * rc1.b * rc1.inv : 0.0, x1c;
         double x2a = 0.0, x2b = 0.0, x2c = 0.0, rsum = 0.0;
+        // software pipeline: the next pair of rows is loaded while the current pair is processed
+        struct Raw {
+            double b, d, cw, ce, cs, cn;
+            bool valid;
+        };
+        auto fetch = [&](int j, Raw &R) {
+            const int mr = mem_row(j, g, op.per_j);
+            R.valid = cvalid && mr >= 0;
+            const size_t cc = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+            R.b = b[cc]; R.d = op.D[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+            R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+        };
+        Raw nx[2];
+        fetch(j0, nx[0]);
+        fetch(j0 + 1, nx[1]);
         for (int jr = j0; jr < j1 + 2; jr += 2) {
             RowC rn[2];
             bool vn[2];
+            const Raw cu[2] = {nx[0], nx[1]};
+            if (jr + 2 < j1 + 2) {
+                fetch(jr + 2, nx[0]);
+                fetch(jr + 3, nx[1]);
+            }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) rn[q] = rowc(jr + q, vn[q]);
+            for (int q = 0; q < 2; ++q) {
+                rn[q] = RowC{cu[q].b, cu[q].d, fast_rcp(cu[q].d), cu[q].cw, cu[q].ce, cu[q].cs, cu[q].cn};
+                vn[q] = cu[q].valid;
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int j = jr + q;                 // newest row
@@ -761,12 +784,39 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const doub
         RowC rc2 = rowc(j0 - 2, v2, x0a);
         RowC rc1 = rowc(j0 - 1, v1, x0b);
         double x1a = 0.0, x1b = 0.0, x1c = 0.0;
+        // software pipeline: the next pair of rows is loaded while the current pair is processed
+        struct Raw {
+            double b, d, cw, ce, cs, cn, x, e;
+            bool valid;
+        };
+        auto fetch = [&](int j, Raw &R) {
+            const int mr = mem_row(j, g, op.per_j);
+            R.valid = cvalid && mr >= 0;
+            const int js = (mr >= 0 ? mr : 2) - 2;
+            const size_t cc = (size_t)(js + 2) * P + colo;
+            R.x = x[cc];
+            R.e = e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
+            R.b = b[cc]; R.d = op.D[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+            R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+        };
+        Raw nx[2];
+        fetch(j0, nx[0]);
+        fetch(j0 + 1, nx[1]);
         for (int jr = j0; jr < j1 + 2; jr += 2) {
             RowC rn[2];
             double xl[2];
             bool vn[2];
+            const Raw cu[2] = {nx[0], nx[1]};
+            if (jr + 2 < j1 + 2) {
+                fetch(jr + 2, nx[0]);
+                fetch(jr + 3, nx[1]);
+            }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) rn[q] = rowc(jr + q, vn[q], xl[q]);
+            for (int q = 0; q < 2; ++q) {
+                rn[q] = RowC{cu[q].b, cu[q].d, fast_rcp(cu[q].d), cu[q].cw, cu[q].ce, cu[q].cs, cu[q].cn};
+                vn[q] = cu[q].valid;
+                xl[q] = cu[q].valid ? cu[q].x + gamma * cu[q].e : 0.0;
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int j = jr + q;
@@ -1249,13 +1299,20 @@ static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double 
     const Tiling T = tiling(g);
     const dim3 grid(T.blocks), blk = block2d();
     hipStream_t st = c->stream;
-    hipLaunchKernelGGL(k_rowsum_bound, grid, blk, 0, st, op, T, c->partials);
-    hipLaunchKernelGGL(k_min_finish1, dim3(1), dim3(256), 0, st, c->partials, T.blocks, c->scal + 12);
-    CFD_HIP(hipGetLastError());
-    CFD_TRY(all_reduce(c, c->scal + 12, 1, 1));
-    if (c->mg_fused && g.ni >= 16 && g.nj >= 16) {
-        CFD_TRY(read_scalars(c, 12, 1, c->h_scal + 12));      // h_scal[12] = -rho
+    const bool fused_path = c->mg_fused && g.ni >= 16 && g.nj >= 16;
+    // the bound of the cached laminar momentum operator is remembered with it
+    const bool known = fused_path && op.D == c->ap && c->ap_cached && c->rho_cached >= 0.0;
+    if (!known) {
+        hipLaunchKernelGGL(k_rowsum_bound, grid, blk, 0, st, op, T, c->partials);
+        hipLaunchKernelGGL(k_min_finish1, dim3(1), dim3(256), 0, st, c->partials, T.blocks, c->scal + 12);
+        CFD_HIP(hipGetLastError());
+        CFD_TRY(all_reduce(c, c->scal + 12, 1, 1));
+    }
+    if (fused_path) {
+        if (known) c->h_scal[12] = -c->rho_cached;
+        else CFD_TRY(read_scalars(c, 12, 1, c->h_scal + 12));      // h_scal[12] = -rho
         const double rho_f = -c->h_scal[12];
+        if (op.D == c->ap && c->ap_cached) c->rho_cached = rho_f;
         if (!(rho_f >= 0.0) || rho_f > c->cheb_rho_max) return CFD_OK;
         // four iterations per launch where no slab cut limits the halo depth to two rows
         if (c->comm.nranks == 1 && c->cheb_stages >= 4 && g.ni >= 64 && g.nj >= 64)
