@@ -177,6 +177,31 @@ def main():
         elapsed = float(t.item())
     n_probe, probe_us = dev.probe_read()
     dev.probe(-1)
+    # ---- outside the timed region: per-phase device times of two more steps (event pairs with a host
+    # sync per phase, which is why they are not collected inside the timed steps) and a plain
+    # device-to-device copy of one plane as the streaming reference figure of this GPU
+    dev.enable_phase_timing(True)
+    dev.phase_times(reset=True)
+    extra_steps, p_its = 2, []
+    for _ in range(extra_steps):
+        advance_one_step(dev, ctl, step)
+        p_its.append(dev.stats()["p_iters"])
+        step += 1
+    phases = dev.phase_times(reset=True)
+    dev.enable_phase_timing(False)
+    copy_gbs = None
+    if rank == 0:
+        a = torch.empty(n * n, dtype=torch.float64, device="cuda")
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * 8.0 * n * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * n * n / (elapsed / args.steps)
 
@@ -219,6 +244,21 @@ def main():
                        "last_continuity_l2": info["cont"], "last_dt": info["dt"]},
             "roofline": roofline,
         }
+        # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes of one
+        # MG-PCG iteration over all levels: finest level 72 (k_cg_pq) + 24 (k_cg_r) + 42 (k_mg_down)
+        # + 50 (k_mg_up) B/cell, coarser levels (42 + 50) / 3 B/cell.
+        pcg_bytes_per_cell_iter = 72 + 24 + 42 + 50 + (42 + 50) / 3.0
+        n_solves = extra_steps * args.max_iter
+        press_s = phases["press"] / n_solves
+        mean_p_it = float(np.mean(p_its))
+        out["pressure_solve"] = {
+            "ms_per_solve": 1e3 * press_s, "iterations": mean_p_it,
+            "algorithmic_bytes_per_cell_per_iteration": pcg_bytes_per_cell_iter,
+            "achieved_GBps": pcg_bytes_per_cell_iter * mean_p_it * n * n / press_s / 1e9 if press_s > 0 else None,
+            "frac_of_hbm_peak": pcg_bytes_per_cell_iter * mean_p_it * n * n / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
+            "note": "includes the pressure right-hand side kernel and the host residual checks of the solve"}
+        out["phase_ms_per_step"] = {k: 1e3 * v / extra_steps for k, v in phases.items()}
+        out["device_copy_GBps"] = copy_gbs
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps, args.max_iter)
         else:
