@@ -12,7 +12,7 @@ The JSON line also carries
   roofline     : the kernel with the largest share of device time, k_cg_pq (fused PCG direction
                  step of the pressure solve: p' = z + beta p, q = A p', (p', q), deferred x update),
                  timed live with HIP-event pairs around every launch inside the timed steps;
-                 achieved = 72 B/cell * Ni*Nj / avg duration (z, p, x, D, c_i, c_j read; p', q, x
+                 achieved = 64 B/cell * Ni*Nj / avg duration (z, p, x, c_i, c_j read; p', q, x
                  written).  --probe 8 / 7 / 1 select the momentum Chebyshev kernel / the multigrid up /
                  down kernels instead.  traffic = HBM bytes per launch from the committed PMC passes
                  of this command (profiles/r1e_pmc8192_bytes_per_cell.csv), quoted only for the
@@ -35,7 +35,7 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SMOOTHER_BYTES_PER_CELL = 50   # k_mg_up: x, e/4, b, c_i, c_j, D read + x' written, for TWO sweeps + prolongation
+SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
 # 8192^2 (profiles/r1e_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
 PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 75.05, 8: 109.71, 7: 56.13, 1: 45.92, 2: 140.25}
@@ -212,7 +212,7 @@ def main():
                         2: "momentum RHS (k_momentum_rhs)", 3: "batched momentum operator (k_bi_apply<2>)",
                         8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>; k_cheb2<2> on j-slab runs)",
                         7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
-        bytes_per_cell = {0: 72, 1: 42, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]
+        bytes_per_cell = {0: 64, 1: 34, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]
         achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
@@ -245,9 +245,9 @@ def main():
             "roofline": roofline,
         }
         # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes of one
-        # MG-PCG iteration over all levels: finest level 72 (k_cg_pq) + 24 (k_cg_r) + 42 (k_mg_down)
-        # + 50 (k_mg_up) B/cell, coarser levels (42 + 50) / 3 B/cell.
-        pcg_bytes_per_cell_iter = 72 + 24 + 42 + 50 + (42 + 50) / 3.0
+        # MG-PCG iteration over all levels: finest level 64 (k_cg_pq) + 24 (k_cg_r) + 34 (k_mg_down)
+        # + 42 (k_mg_up) B/cell (diagonal recomputed from the face planes), coarser levels (42 + 50) / 3 B/cell.
+        pcg_bytes_per_cell_iter = 64 + 24 + 34 + 42 + (42 + 50) / 3.0
         n_solves = extra_steps * args.max_iter
         press_s = phases["press"] / n_solves
         mean_p_it = float(np.mean(p_its))

@@ -589,6 +589,8 @@ int cfd_set_pressure_bc(cfd_ctx *ctx, const int32_t *mask_imin, const int32_t *m
         else CFD_HIP(hipMemsetAsync(c->pmask[s], 0, n * 4, c->stream));
     }
     CFD_HIP(hipStreamSynchronize(c->stream));
+    c->pin_i_any = pin_i;
+    c->pin_j_rel = pin_j - (c->comm.nranks > 1 ? c->comm.j_offset : 0);
     const bool slab = c->comm.nranks > 1;
     if (slab && per_j) { set_error("periodicity along j is not supported across j-slabs"); return CFD_E_ARG; }
     // slab runs: pin_j is the global row; the owner pins, everyone else passes it through

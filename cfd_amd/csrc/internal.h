@@ -54,6 +54,14 @@ struct OpDev {
     int per_i, per_j;
 };
 
+// finest pressure level: diagonal recomputed from the face planes (linalg.hip, diag_from_faces);
+// (pi, pj) = reference cell in this slab's logical coordinates (may lie outside it), c* = its couplings
+struct DiagFix {
+    int on = 0, pi = -1, pj = -1;
+    double cW = 0.0, cE = 0.0, cS = 0.0, cN = 0.0;     // the neighbours' (zeroed) couplings to the reference cell
+    double oW = 0.0, oE = 0.0, oS = 0.0, oN = 0.0;     // the reference cell's own (zeroed) face values
+};
+
 struct FlowBCSide {
     const int32_t *kind_uv, *kind_p;
     const double *ua, *ub, *va, *vb, *pa, *pb, *nx, *ny;
@@ -138,6 +146,9 @@ struct Ctx {
     Comm comm;
     bool p_built = false;
     bool p_symmetric = true;
+    DiagFix p_diag;
+    int recompute_diag = 1;
+    int pin_i_any = -1, pin_j_rel = -1;   // reference cell as given (slab runs: row relative to this slab)
 
     // reductions
     double *partials = nullptr;  // [q][MAX_PARTIALS]

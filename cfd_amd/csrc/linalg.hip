@@ -647,6 +647,30 @@ __device__ __forceinline__ RowC load_rowc(const OpDev &op, const double *b, size
     return r;
 }
 
+// Diagonal of the finest pressure level from its face planes: k_pressure_coeffs forms
+// D = ((c_W + c_E) + c_S) + c_N from the very values it stores (boundary faces included), so the D
+// plane need not be read (8 of the 42 / 50 / 72 B per cell of the finest-level kernels).  The one
+// exception is the detached reference cell: its four couplings were zeroed in the planes but still
+// count in D of the cell and of its four neighbours; DiagFix carries them (same summation order, so
+// the recomputed diagonal has the bits of the stored one).
+__device__ __forceinline__ double diag_from_faces(double cw, double ce, double cs, double cn, int col, int row,
+                                                  const DiagFix &f, const OpDev &op) {
+    if (f.pi >= 0) {
+        int di = col - f.pi, dj = row - f.pj;
+        if (op.per_i) { if (di == op.g.ni - 1) di = -1; else if (di == 1 - op.g.ni) di = 1; }
+        if (op.per_j) { if (dj == op.g.nj - 1) dj = -1; else if (dj == 1 - op.g.nj) dj = 1; }
+        if (dj == 0) {
+            if (di == 0) { cw += f.oW; ce += f.oE; cs += f.oS; cn += f.oN; }
+            else if (di == -1) ce += f.cW;
+            else if (di == 1) cw += f.cE;
+        } else if (di == 0) {
+            if (dj == -1) cn += f.cS;
+            else if (dj == 1) cs += f.cN;
+        }
+    }
+    return ((cw + ce) + cs) + cn;
+}
+
 __device__ __forceinline__ double jac(double xc, double xs, double xn, const RowC &r, double omega) {
     const double xl = lane_left(xc), xr = lane_right(xc);
     const double ax = r.d * xc - (r.cw * xl + r.ce * xr + r.cs * xs + r.cn * xn);
@@ -671,8 +695,8 @@ static inline MarchGeo march_geo(const Geo &g) {
 }
 
 template <bool FINE>
-__global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const double *b, double omega, double omega2, double *x, Geo gc,
-                                                 double *bc) {
+__global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, DiagFix df, const double *b, double omega, double omega2,
+                                                 double *x, Geo gc, double *bc) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
@@ -685,28 +709,37 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
         const size_t colo = (size_t)(cvalid ? col : 0) + 2;
         const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
-        auto rowc = [&](int j, bool &valid) -> RowC {
-            const int mr = mem_row(j, g, op.per_j);
-            valid = cvalid && mr >= 0;
-            return load_rowc(op, b, (size_t)(mr >= 0 ? mr : 2) * P + colo, mr < g.nj + 3 ? P : 0);
-        };
-        bool v2, v1;
-        RowC rc2 = rowc(j0 - 2, v2);
-        RowC rc1 = rowc(j0 - 1, v1);
-        double x1a = v2 ? omega * rc2.b * rc2.inv : 0.0, x1b = v1 ? omega * rc1.b * rc1.inv : 0.0, x1c;
-        double x2a = 0.0, x2b = 0.0, x2c = 0.0, rsum = 0.0;
         // software pipeline: the next pair of rows is loaded while the current pair is processed
         struct Raw {
             double b, d, cw, ce, cs, cn;
+            int row;
             bool valid;
         };
         auto fetch = [&](int j, Raw &R) {
             const int mr = mem_row(j, g, op.per_j);
             R.valid = cvalid && mr >= 0;
+            R.row = (mr >= 0 ? mr : 2) - 2;
             const size_t cc = (size_t)(mr >= 0 ? mr : 2) * P + colo;
-            R.b = b[cc]; R.d = op.D[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+            R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+            // the outermost halo row of a high slab cut has no north face in memory: its D is read
+            R.d = (FINE && df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
+            if (!(FINE && df.on) || mr == g.nj + 3) R.row = -1000000;
         };
+        auto mk = [&](const Raw &R) -> RowC {
+            const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
+            return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
+        };
+        bool v2, v1;
+        Raw pre;
+        fetch(j0 - 2, pre);
+        RowC rc2 = mk(pre);
+        v2 = pre.valid;
+        fetch(j0 - 1, pre);
+        RowC rc1 = mk(pre);
+        v1 = pre.valid;
+        double x1a = v2 ? omega * rc2.b * rc2.inv : 0.0, x1b = v1 ? omega * rc1.b * rc1.inv : 0.0, x1c;
+        double x2a = 0.0, x2b = 0.0, x2c = 0.0, rsum = 0.0;
         Raw nx[2];
         fetch(j0, nx[0]);
         fetch(j0 + 1, nx[1]);
@@ -720,7 +753,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                rn[q] = RowC{cu[q].b, cu[q].d, fast_rcp(cu[q].d), cu[q].cw, cu[q].ce, cu[q].cs, cu[q].cn};
+                rn[q] = mk(cu[q]);
                 vn[q] = cu[q].valid;
             }
 #pragma unroll
@@ -753,7 +786,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, const do
 }
 
 template <bool FINE>
-__global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const double *b, const double *x, Geo gc,
+__global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
                                                const double *e, double gamma, double omega, double omega2, double *xn,
                                                double *partials) {
     const Geo g = op.g;
@@ -770,35 +803,41 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const doub
         const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + 2;
         const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
-        auto rowc = [&](int j, bool &valid, double &x0) -> RowC {
-            const int mr = mem_row(j, g, op.per_j);
-            valid = cvalid && mr >= 0;
-            const int js = (mr >= 0 ? mr : 2) - 2;     // -2, -1 / nj, nj+1 are halo rows at a slab cut
-            const size_t c = (size_t)(js + 2) * P + colo;
-            const double xv = x[c] + gamma * e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
-            x0 = valid ? xv : 0.0;
-            return load_rowc(op, b, c, mr < g.nj + 3 ? P : 0);
-        };
-        bool v2, v1;
-        double x0a, x0b, x0c;
-        RowC rc2 = rowc(j0 - 2, v2, x0a);
-        RowC rc1 = rowc(j0 - 1, v1, x0b);
-        double x1a = 0.0, x1b = 0.0, x1c = 0.0;
         // software pipeline: the next pair of rows is loaded while the current pair is processed
         struct Raw {
             double b, d, cw, ce, cs, cn, x, e;
+            int row;
             bool valid;
         };
         auto fetch = [&](int j, Raw &R) {
             const int mr = mem_row(j, g, op.per_j);
             R.valid = cvalid && mr >= 0;
-            const int js = (mr >= 0 ? mr : 2) - 2;
+            const int js = (mr >= 0 ? mr : 2) - 2;     // -2, -1 / nj, nj+1 are halo rows at a slab cut
             const size_t cc = (size_t)(js + 2) * P + colo;
             R.x = x[cc];
             R.e = e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
-            R.b = b[cc]; R.d = op.D[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+            R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+            R.d = (FINE && df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
+            R.row = (!(FINE && df.on) || mr == g.nj + 3) ? -1000000 : js;
         };
+        auto mk = [&](const Raw &R) -> RowC {
+            const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
+            return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
+        };
+        bool v2, v1;
+        double x0a, x0b, x0c;
+        Raw pre;
+        fetch(j0 - 2, pre);
+        RowC rc2 = mk(pre);
+        v2 = pre.valid;
+        (void)v2;
+        x0a = pre.valid ? pre.x + gamma * pre.e : 0.0;
+        fetch(j0 - 1, pre);
+        RowC rc1 = mk(pre);
+        v1 = pre.valid;
+        x0b = pre.valid ? pre.x + gamma * pre.e : 0.0;
+        double x1a = 0.0, x1b = 0.0, x1c = 0.0;
         Raw nx[2];
         fetch(j0, nx[0]);
         fetch(j0 + 1, nx[1]);
@@ -813,7 +852,7 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, const doub
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                rn[q] = RowC{cu[q].b, cu[q].d, fast_rcp(cu[q].d), cu[q].cw, cu[q].ce, cu[q].cs, cu[q].cn};
+                rn[q] = mk(cu[q]);
                 vn[q] = cu[q].valid;
                 xl[q] = cu[q].valid ? cu[q].x + gamma * cu[q].e : 0.0;
             }
@@ -1485,6 +1524,23 @@ int build_pressure_hierarchy(Ctx *c) {
     Level &L0 = c->levels[0];
     CFD_TRY(launch_pressure_coeffs(c, L0));
     hipStream_t st = c->stream;
+    // finest-level diagonal from the face planes (see diag_from_faces): every rank needs the four
+    // couplings of the detached reference cell, which only its owner knows
+    c->p_diag = DiagFix{};
+    if (c->recompute_diag) {
+        DiagFix f{};
+        f.on = 1; f.pi = -1; f.pj = -1;
+        if (!c->has_dirichlet) {
+            if (c->pin_i < 0) CFD_HIP(hipMemsetAsync(c->scal + 64, 0, 8 * sizeof(double), st));
+            CFD_TRY(all_reduce(c, c->scal + 64, 8, 0));
+            double pc[8];
+            CFD_TRY(read_scalars(c, 64, 8, pc));
+            f.pi = c->pin_i_any; f.pj = c->pin_j_rel;
+            f.cW = pc[0]; f.cE = pc[1]; f.cS = pc[2]; f.cN = pc[3];
+            f.oW = pc[4]; f.oE = pc[5]; f.oS = pc[6]; f.oN = pc[7];
+        }
+        c->p_diag = f;
+    }
     const int la = c->l_agg;
     CFD_TRY(halo_exchange(c, L0.g, 2, L0.ci, L0.cj, L0.D));
     for (int l = 0; l + 1 < (int)c->levels.size(); ++l) {
@@ -1558,10 +1614,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             CFD_TRY(halo_exchange(c, L.g, 2, const_cast<double *>(rhs[l])));
             if (l == 0) {
                 c->probe_begin(1);
-                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, om2, cur[l], cg, cb);
+                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
                 c->probe_end(1);
             } else {
-                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], om, om2, cur[l], cg, cb);
+                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, DiagFix{}, rhs[l], om, om2, cur[l], cg, cb);
             }
             CFD_HIP(hipGetLastError());
         } else {
@@ -1615,12 +1671,12 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             CFD_TRY(halo_exchange(c, L.g, 2, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
-                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
+                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);
                 c->probe_end(7);
                 *dot_blocks = (int)grid.x;
             } else {
-                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
+                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, DiagFix{}, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);
             }
             std::swap(cur[l], oth[l]);
@@ -1715,7 +1771,7 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 // 72 B/cell (z, p, x, D, c_i, c_j read; p', q, x written) instead of 24 + 40 for k_cg_p + k_cg_q and
 // 16 of the 48 of k_cg_xr, whose remainder is k_cg_r below.  p' goes to a second plane: neighbouring
 // strips recompute p' on their halo from the old p.
-__global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, const CgScal *s, int gen, int first, const double *z,
+__global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen, int first, const double *z,
                                                const double *pold, double *pnew, double *q, double *x, double *partials) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1749,8 +1805,10 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, const CgSc
             R.po = first ? 0.0 : pold[cc];
             R.z = z[cc];
             R.xv = first ? 0.0 : x[cc];
-            R.d = op.D[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+            R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+            // rows j0-1 .. j1 only: the outermost halo row is never touched here
+            R.d = df.on ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, (mr >= 0 ? mr : 2) - 2, df, op) : op.D[cc];
         };
         RowIn nxt;
         fetch(j0 - 1, nxt);
@@ -1850,7 +1908,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             p = pbuf[gen];
             CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
             c->probe_begin(0);
-            hipLaunchKernelGGL(k_cg_pq, mgrid, dim3(256), 0, st, op, mgeo, S, gen, it == 0, z, pold, p, q, x, c->partials);
+            hipLaunchKernelGGL(k_cg_pq, mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, z, pold, p, q, x, c->partials);
             c->probe_end(0);
             CFD_HIP(hipGetLastError());
             CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));
@@ -1977,7 +2035,7 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                     const OpDev op = level_op(c, c->levels[0]);
                     if (c->levels.size() > 1 && level_fusable(c, c->levels[0].g, coarse_view(c, 1))) {
                         const MarchGeo mgeo = march_geo(g);
-                        hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->kry[1],
+                        hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->p_diag, c->kry[1],
                                            c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_gamma, c->mg_omega, c->mg_omega, c->kry[5], c->partials);
                     } else {
                         hipLaunchKernelGGL(k_mg_jacobi, grid, blk, 0, st, op, T, c->kry[1], c->kry[4], c->mg_omega, c->kry[5]);

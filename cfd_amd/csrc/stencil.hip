@@ -583,6 +583,8 @@ __global__ void k_pin_operator(Geo g, int pi, int pj, int per_i, int per_j, doub
     pin_coef[1] = (pi < g.ni - 1) ? ci[fe] : (per_i ? ci[fe2] : 0.0);
     pin_coef[2] = (pj > 0) ? cj[fs] : (per_j ? cj[fs2] : 0.0);
     pin_coef[3] = (pj < g.nj - 1) ? cj[fn] : (per_j ? cj[fn2] : 0.0);
+    // the cell's own four face values (on a periodic seam they can differ from the neighbour's copy)
+    pin_coef[4] = ci[fw]; pin_coef[5] = ci[fe]; pin_coef[6] = cj[fs]; pin_coef[7] = cj[fn];
     ci[fw] = 0.0; ci[fe] = 0.0; cj[fs] = 0.0; cj[fn] = 0.0;
     if (per_i && pi == 0) ci[fw2] = 0.0;
     if (per_i && pi == g.ni - 1) ci[fe2] = 0.0;
