@@ -89,6 +89,18 @@ void set_error(const char *fmt, ...);
         if (rc__ != CFD_OK) return rc__; \
     } while (0)
 
+// lane i <- lane i-1 / lane i+1 through DPP wave shifts (VALU, no LDS round trip)
+__device__ __forceinline__ double lane_left(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_right(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // ------------------------------------------------------------------ multigrid level
 struct Level {
     Geo g;
@@ -184,6 +196,13 @@ struct Ctx {
     int cheb_max_iters = 80;     // ... and predicted iteration count below this; else BiCGStab
     int stats_last_solver = 0;   // 1 = the last transport solve was Chebyshev
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
+    int march_flux = 1;          // marching form of the Rhie-Chow flux kernels (momentum / pressure RHS, continuity)
+    // momentum right-hand sides computed ahead of time by the fused continuity pass of the previous
+    // inner iteration (valid while the fields, a_P and dt are the ones it saw)
+    int rhs_lookahead = 1;
+    bool rhs_ahead = false;
+    double rhs_dt = -1.0;
+    int rhs_cur = -1;
     double k_clip = 1e-10, omega_clip = 1e-10;
     double dt_ap = -1.0;          // dt the a_P plane was built with
     bool ap_cached = false;       // laminar: a_P / a_i / a_j are current for dt_ap
@@ -228,7 +247,7 @@ int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *
 int launch_flow_bc(Ctx *c, double *u, double *v, double *p);
 int launch_turb_bc(Ctx *c);
 int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]);
-int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, const double *p);
+int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, const double *p, double *cont = nullptr);
 int launch_turb_rhs(Ctx *c, double dt);
 int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b);
 int launch_pressure_coeffs(Ctx *c, Level &L);

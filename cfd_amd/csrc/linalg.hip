@@ -625,18 +625,6 @@ __device__ __forceinline__ double fast_rcp(double d) {
     return r;
 }
 
-// lane i <- lane i-1 / lane i+1 through DPP wave shifts (VALU, no LDS round trip)
-__device__ __forceinline__ double lane_left(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_right(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
 // Unconditional loads from a clamped (always valid) cell: lanes / rows outside the domain
 // read finite garbage that only ever multiplies x = 0.
 // `up` = distance to the row above (0 for the outermost halo row, whose north face is never used).

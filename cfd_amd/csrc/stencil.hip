@@ -378,6 +378,211 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
 }
 
 // ----------------------------------------------------------------------------------
+// Marching form of the Rhie-Chow flux kernels (momentum RHS, pressure RHS, continuity).
+// One wavefront owns a strip of 62 columns plus one halo lane on each side and walks down the
+// rows of a segment: every plane row is loaded once per wave as one coalesced run, horizontal
+// neighbours come from DPP wave shifts, vertical neighbours from registers of the previous
+// rows.  Each face flux is evaluated ONCE (the west and the south face of every cell; the east
+// face is the right lane's west face, the north face the next row's south face) with the very
+// expressions of flux_i / flux_j above, so all results keep the bits of the tile kernels.
+// The tile kernels read 6 rows for 4 and every face twice (1.5-1.9x the algorithmic bytes at
+// 8192^2, profiles/r1e_pmc8192_bytes_per_cell.csv); this form reads (Ls + 2) / Ls rows.
+//   MODE 0: continuity sum only            (13 planes read,            104 B/cell)
+//   MODE 1: b = -div F (pressure RHS)      (13 read, 1 written,        112 B/cell)
+//   MODE 2: momentum RHS b_u, b_v + the continuity sum of the same fluxes (13 (+k) read, 2 written)
+// ----------------------------------------------------------------------------------
+constexpr int FXW = 62;
+
+struct FluxMarch {
+    int nstrips, nsegs, Ls, blocks;
+};
+static inline FluxMarch flux_march_geo(const Geo &g) {
+    FluxMarch m;
+    m.nstrips = (g.ni + FXW - 1) / FXW;
+    int Ls = 32;
+    while (Ls > 4 && (long)m.nstrips * ((g.nj + Ls - 1) / Ls) < 8192) Ls /= 2;
+    m.Ls = Ls;
+    m.nsegs = (g.nj + Ls - 1) / Ls;
+    const long nb = ((long)m.nstrips * m.nsegs + 3) / 4;
+    m.blocks = (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
+    return m;
+}
+
+struct FluxRow {
+    double u, v, p, ap;            // fields of the row
+    double wri, nix, niy, si;      // west i-face of the cell
+    double wnj, njx, njy, sj;      // south j-face of the cell
+    double vol, k;
+};
+
+struct MomArgs {
+    const double *kgrad, *ai, *aj;
+    double inv_dt, force_u, force_v;
+    int per_i, per_j;
+    double *bu, *bv;
+};
+
+template <int MODE, bool KG>
+__global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, FluxMarch fm, MomArgs ma, double *bout,
+                                                    double *partials) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    const int rc = f.rc;
+    double acc = 0.0;
+    for (int item = blockIdx.x * 4 + wave; item < fm.nstrips * fm.nsegs; item += nw) {
+        const int strip = item % fm.nstrips, seg = item / fm.nstrips;
+        const int iraw = strip * FXW - 1 + lane;          // -1 .. ni : ghost columns included
+        const int ic = iraw < g.ni ? iraw : g.ni;
+        const size_t colo = (size_t)(ic + 2);
+        const bool out = lane >= 1 && lane <= FXW && iraw < g.ni;
+        const bool ilo = iraw == 0, ihi = iraw == g.ni;
+        const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
+        auto fetch = [&](int j, FluxRow &R) {
+            const size_t c = (size_t)(j + 2) * P + colo;
+            R.u = f.u[c]; R.v = f.v[c]; R.p = f.p[c];
+            R.ap = rc ? f.ap[c] : 1.0;
+            R.wri = m.wri[c]; R.nix = m.nix[c]; R.niy = m.niy[c]; R.si = m.si[c];
+            R.wnj = m.wnj[c]; R.njx = m.njx[c]; R.njy = m.njy[c]; R.sj = m.sj[c];
+            R.vol = m.vol[c];
+            R.k = KG ? (2.0 / 3.0) * ma.kgrad[c] : 0.0;
+        };
+        FluxRow nxt, cur{}, prv{};
+        double u2 = 0.0, v2 = 0.0, p2 = 0.0, k2 = 0.0;      // row j-2 (MODE 2)
+        double fw_p = 0.0, fs_p = 0.0;                       // west / south flux of row j-1
+        fetch(j0 - 1, nxt);
+        for (int j = j0 - 1; j <= j1; ++j) {
+            cur = nxt;
+            if (j < j1) fetch(j + 1, nxt);
+            // west-face flux of row j (flux_i)
+            const double uL = lane_left(cur.u), vL = lane_left(cur.v), pL = lane_left(cur.p);
+            double fw_c;
+            {
+                const double wr = cur.wri, wl = 1.0 - wr;
+                const double ui = wl * uL + wr * cur.u;
+                const double vi = wl * vL + wr * cur.v;
+                fw_c = ui * cur.nix + vi * cur.niy;
+                if (rc) {
+                    const double apL = lane_left(cur.ap);
+                    double af = ilo ? cur.ap : (ihi ? apL : wl * apL + wr * cur.ap);
+                    af = af > TINY ? af : TINY;
+                    const double s = cur.si;
+                    fw_c = fw_c - (s * s) / af * (cur.p - pL);
+                }
+            }
+            // south-face flux of row j (flux_j); face j = nj is the north face of the last row
+            double fs_c;
+            {
+                const bool lo = g.blo(j), hi = (j == g.nj) && !g.cuthi;
+                const double wn = cur.wnj, ws = 1.0 - wn;
+                const double uj = ws * prv.u + wn * cur.u;
+                const double vj = ws * prv.v + wn * cur.v;
+                fs_c = uj * cur.njx + vj * cur.njy;
+                if (rc) {
+                    double af = lo ? cur.ap : (hi ? prv.ap : ws * prv.ap + wn * cur.ap);
+                    af = af > TINY ? af : TINY;
+                    const double s = cur.sj;
+                    fs_c = fs_c - (s * s) / af * (cur.p - prv.p);
+                }
+            }
+            // output row jo = j - 1: cell data in prv, north neighbour in cur, south neighbour in *2
+            const int jo = j - 1;
+            const double fe_p = lane_right(fw_p);
+            if (MODE == 2) {
+                // DPP shifts must run in all lanes: hoisted out of the output branch
+                const double uW = lane_left(prv.u), uE = lane_right(prv.u);
+                const double vW = lane_left(prv.v), vE = lane_right(prv.v);
+                const double pW = lane_left(prv.p), pE = lane_right(prv.p);
+                const double wriE = lane_right(prv.wri), nixE = lane_right(prv.nix), niyE = lane_right(prv.niy);
+                const double kW = KG ? lane_left(prv.k) : 0.0, kE = KG ? lane_right(prv.k) : 0.0;
+                if (jo >= j0 && out) {
+                    const double fw = fw_p, fe = fe_p, fs = fs_p, fn = fs_c;
+                    const double vol = prv.vol;
+                    const size_t c = (size_t)(jo + 2) * P + colo;
+                    // upwind (solver.py:649-669)
+                    double advu, advv;
+                    {
+                        const double pc = prv.u;
+                        const double pw = fw >= 0.0 ? uW : pc, pe = fe >= 0.0 ? pc : uE;
+                        const double ps = fs >= 0.0 ? u2 : pc, pn = fn >= 0.0 ? pc : cur.u;
+                        const double div = fe * pe - fw * pw + fn * pn - fs * ps;
+                        advu = -div / vol;
+                    }
+                    {
+                        const double pc = prv.v;
+                        const double pw = fw >= 0.0 ? vW : pc, pe = fe >= 0.0 ? pc : vE;
+                        const double ps = fs >= 0.0 ? v2 : pc, pn = fn >= 0.0 ? pc : cur.v;
+                        const double div = fe * pe - fw * pw + fn * pn - fs * ps;
+                        advv = -div / vol;
+                    }
+                    // Green-Gauss gradient of p (and of 2/3 k) (solver.py:322-358)
+                    double gx, gy;
+                    {
+                        const double pc = prv.p;
+                        const double pw = (1.0 - prv.wri) * pW + prv.wri * pc;
+                        const double pe = (1.0 - wriE) * pc + wriE * pE;
+                        const double ps = (1.0 - prv.wnj) * p2 + prv.wnj * pc;
+                        const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.p;
+                        gx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
+                        gy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                    }
+                    if (KG) {
+                        const double pc = prv.k;
+                        const double pw = (1.0 - prv.wri) * kW + prv.wri * pc;
+                        const double pe = (1.0 - wriE) * pc + wriE * kE;
+                        const double ps = (1.0 - prv.wnj) * k2 + prv.wnj * pc;
+                        const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.k;
+                        const double kx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
+                        const double ky = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        gx = gx + kx;
+                        gy = gy + ky;
+                    }
+                    const double su = advu - gx + ma.force_u, sv = advv - gy + ma.force_v;
+                    double b_u = vol * ma.inv_dt * prv.u + vol * su;
+                    double b_v = vol * ma.inv_dt * prv.v + vol * sv;
+                    if (!ma.per_i) {
+                        if (iraw == 0) { const double a = ma.ai[c]; b_u += a * uW; b_v += a * vW; }
+                        if (iraw == g.ni - 1) { const double a = ma.ai[c + 1]; b_u += a * uE; b_v += a * vE; }
+                    }
+                    if (!ma.per_j) {
+                        if (g.blo(jo)) { const double a = ma.aj[c]; b_u += a * u2; b_v += a * v2; }
+                        if (g.bhi(jo)) { const double a = ma.aj[c + P]; b_u += a * cur.u; b_v += a * cur.v; }
+                    }
+                    ma.bu[c] = b_u;
+                    ma.bv[c] = b_v;
+                    const double div = (fe - fw + fn - fs) / vol;
+                    acc += div * div;
+                }
+                u2 = prv.u; v2 = prv.v; p2 = prv.p; k2 = prv.k;
+            } else if (jo >= j0 && out) {
+                const double vol = prv.vol;
+                const double div = (fe_p - fw_p + fs_c - fs_p) / vol;
+                if (MODE == 0) acc += div * div;
+                else bout[(size_t)(jo + 2) * P + colo] = vol * (-div);
+            }
+            fw_p = fw_c; fs_p = fs_c;
+            prv = cur;
+        }
+    }
+    if (MODE != 1) {
+        __shared__ double sm[4];
+        const double w = wave_sum(acc);
+        if (lane == 0) sm[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+static int finish_continuity(Ctx *c, int nb, double *out) {
+    c->n_red_blocks = nb;
+    CFD_TRY(reduce_finish(c, 1, 0));
+    double s;
+    CFD_TRY(read_scalars(c, 0, 1, &s));
+    *out = sqrt(s / global_cells(c));
+    return CFD_OK;
+}
+
+// ----------------------------------------------------------------------------------
 // momentum right-hand sides (solver.py:672-691 advective RHS, 868-876 sources,
 // 723-730 transient + boundary terms), fused: nothing but b_u, b_v is written.
 // kgrad != nullptr adds grad(2/3 k) to grad p (solver.py:871-872, 1621-1626).
@@ -418,14 +623,29 @@ __global__ void k_momentum_rhs(Geo g, MeshDev m, FluxIn f, const double *kgrad, 
     bv[c] = b_v;
 }
 
-int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, const double *p) {
+int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, const double *p, double *cont) {
     // the predictor's Rhie-Chow flux uses p_field = fields["p"] (solver.py:1602-1607);
     // the 2/3 k term enters through the gradient only.
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
+    if (c->march_flux) {
+        // marching kernel: the continuity sum of the same fluxes comes for free (cont != nullptr reads it)
+        const FluxMarch fm = flux_march_geo(c->g);
+        MomArgs ma{c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j, c->bu, c->bv};
+        if (c->turbulent)
+            hipLaunchKernelGGL((k_flux_march<2, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
+                               (double *)nullptr, c->partials);
+        else
+            hipLaunchKernelGGL((k_flux_march<2, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
+                               (double *)nullptr, c->partials);
+        CFD_HIP(hipGetLastError());
+        if (cont) return finish_continuity(c, fm.blocks, cont);
+        return CFD_OK;
+    }
     hipLaunchKernelGGL(k_momentum_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f,
                        c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j,
                        c->bu, c->bv);
     CFD_HIP(hipGetLastError());
+    if (cont) return launch_continuity(c, u, v, p, cont);
     return CFD_OK;
 }
 
@@ -511,7 +731,13 @@ __global__ void k_pin_rhs(Geo g, int pi, int pj, double value, const double *pin
 
 int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b) {
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
-    hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
+    if (c->march_flux) {
+        const FluxMarch fm = flux_march_geo(c->g);
+        hipLaunchKernelGGL((k_flux_march<1, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, MomArgs{}, b,
+                           c->partials);
+    } else {
+        hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
+    }
     CFD_HIP(hipGetLastError());
     if (!c->has_dirichlet && c->pin_i >= 0) {      // pin_i < 0: the reference cell lives on another slab
         const Level &L = c->levels[0];
@@ -692,6 +918,13 @@ int launch_continuity(Ctx *c, const double *u, const double *v, const double *p,
     int tx;
     const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
+    if (c->march_flux) {
+        const FluxMarch fm = flux_march_geo(c->g);
+        hipLaunchKernelGGL((k_flux_march<0, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, MomArgs{},
+                           (double *)nullptr, c->partials);
+        CFD_HIP(hipGetLastError());
+        return finish_continuity(c, fm.blocks, out);
+    }
     hipLaunchKernelGGL(k_continuity, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), f, c->partials, tx, tiles);
     CFD_HIP(hipGetLastError());
     c->n_red_blocks = nb;
