@@ -64,6 +64,7 @@ SIGNATURES = {
     "cfd_set_multigrid": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
     "cfd_set_transport_solver": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int]),
     "cfd_set_smoother_omega2": (C.c_int, [_vp, C.c_double]),
+    "cfd_set_flux_kernels": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cfd_set_turbulence_clip": (C.c_int, [_vp, C.c_double, C.c_double]),
     "cfd_set_flow_bc": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip] + [_dp] * 8),
     "cfd_set_periodicity": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),

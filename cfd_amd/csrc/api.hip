@@ -551,6 +551,13 @@ int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2) {
     return CFD_OK;
 }
 
+int cfd_set_flux_kernels(cfd_ctx *ctx, int marching, int lookahead) {
+    CTX_MUT(ctx);
+    c->march_flux = marching ? 1 : 0;
+    c->rhs_lookahead = lookahead ? 1 : 0;
+    return CFD_OK;
+}
+
 int cfd_set_turbulence_clip(cfd_ctx *ctx, double k_min, double omega_min) {
     CTX_MUT(ctx);
     c->k_clip = k_min; c->omega_clip = omega_min;

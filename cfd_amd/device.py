@@ -160,6 +160,9 @@ class Device:
         check(self.lib.cfd_set_transport_solver(self._h, int(bool(warm_start)), int(bool(chebyshev)), float(rho_max),
                                                 int(max_iters)))
 
+    def set_flux_kernels(self, marching=True, lookahead=True):
+        check(self.lib.cfd_set_flux_kernels(self._h, int(bool(marching)), int(bool(lookahead))))
+
     def set_turbulence_clip(self, k_min, omega_min):
         check(self.lib.cfd_set_turbulence_clip(self._h, float(k_min), float(omega_min)))
 

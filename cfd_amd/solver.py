@@ -272,6 +272,8 @@ def configure_device(dev, config, geometry, nu, turb_on):
     tr = solver_cfg.get("transport", {})
     dev.set_transport_solver(tr.get("warm_start", True), tr.get("chebyshev", True), tr.get("rho_max", 0.95),
                              tr.get("max_iters", 80))
+    fk = solver_cfg.get("flux_kernels", {})
+    dev.set_flux_kernels(fk.get("marching", True), fk.get("lookahead", True))
     params = config.get("turbulence", {}).get("params", {})
     dev.set_turbulence_clip(params.get("k_min", 1.0e-10), params.get("omega_min", 1.0e-10))
     tables = BoundaryTables(config["boundary"], dev.ni, dev.nj_global, geometry, nu, turb_on)

@@ -170,6 +170,13 @@ int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int c
  * spectrum; omega2 <= 0 (default): plain damped Jacobi.  The single-block coarsest solve always uses
  * `omega`.  (Replaces pyamg's smoother choice, solver.py:821-833.)                                  */
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
+/* Form of the Rhie-Chow flux kernels (solver.py:455-513, 672-691, 926-933, 1205-1215).
+ *   marching  : 1 (default) = one wavefront per 62-column strip walking down the rows, every face flux
+ *               evaluated once; 0 = the 64x4-tile kernels (same bits, 1.5-1.9x the HBM traffic);
+ *   lookahead : 1 (default) = the continuity pass at the end of an inner iteration also writes the
+ *               momentum right-hand sides of the next one (same fields, a_P and dt); they are used only
+ *               if nothing they depend on changed in between.  Results are identical either way.   */
+int cfd_set_flux_kernels(cfd_ctx *ctx, int marching, int lookahead);
 /* Transport (momentum, k-omega) solver policy; replaces the reference's spilu + scipy bicgstab
  * with x0 = 0 (solver.py:785-818), same stopping test |b - A x| <= tol |b|.
  *   warm_start : start from the previous field instead of zero;
