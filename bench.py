@@ -15,7 +15,7 @@ The JSON line also carries
                  achieved = 64 B/cell * Ni*Nj / avg duration (z, p, x, c_i, c_j read; p', q, x
                  written).  --probe 8 / 7 / 1 select the momentum Chebyshev kernel / the multigrid up /
                  down kernels instead.  traffic = HBM bytes per launch from the committed PMC passes
-                 of this command (profiles/r1e_pmc8192_bytes_per_cell.csv), quoted only for the
+                 of this command (profiles/r1g_pmc8192_bytes_per_cell.csv), quoted only for the
                  single-GPU default size they were measured on.
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
                  factor-once LU pressure) timed on this host, bounded sample.
@@ -37,8 +37,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
-# 8192^2 (profiles/r1e_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 75.05, 8: 109.71, 7: 56.13, 1: 45.92, 2: 140.25}
+# 8192^2 (profiles/r1g_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 61.89, 8: 110.41, 7: 45.88, 1: 37.03, 2: 117.62}
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1):
@@ -209,7 +209,7 @@ def main():
     if rank == 0:
         kernel_names = {0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq)",
                         1: "MG pre-smoother, finest level: 2 fused Jacobi sweeps + residual + restrict (k_mg_down<true>)",
-                        2: "momentum RHS (k_momentum_rhs)", 3: "batched momentum operator (k_bi_apply<2>)",
+                        2: "momentum RHS + continuity sum, marching Rhie-Chow flux kernel (k_flux_march<2>)", 3: "batched momentum operator (k_bi_apply<2>)",
                         8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>; k_cheb2<2> on j-slab runs)",
                         7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
         bytes_per_cell = {0: 64, 1: 34, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104}[args.probe]

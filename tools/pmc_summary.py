@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_round.sh run into profiles/<tag>_*: kernel stats, FETCH_SIZE / WRITE_SIZE per
+kernel and HBM bytes per cell and launch.  FETCH_SIZE is calibrated on the pure streaming kernels of the
+same run whose read bytes are known (MI355X_MICROARCH.md, HBM: widths other than 16 B per lane are
+uncalibrated - calibrate on a known byte count in the same access pattern); WRITE_SIZE is exact here.
+
+    python tools/pmc_summary.py r1g [cells]
+"""
+import csv
+import glob
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+cells = float(sys.argv[2]) if len(sys.argv) > 2 else 8192.0 * 8192.0
+# algorithmic bytes per cell and launch
+ALGO = {"k_chebk<2, 4>": 104, "k_cg_pq": 64, "k_mg_up<true>": 42, "k_mg_down<true>": 34, "k_cg_r": 24, "k_cg_init": 24,
+        "k_cg_xlast": 24, "k_flux_march<0, false>": 104, "k_flux_march<1, false>": 112, "k_flux_march<2, false>": 120,
+        "k_continuity": 104, "k_pressure_rhs": 112, "k_momentum_rhs": 120, "k_correct": 136, "k_diffusion_ap": 88,
+        "k_dt": 88, "k_rowsum_bound": 24, "k_pressure_coeffs": 64}
+KNOWN_READS = {"k_cg_r": 16.0, "k_cg_xlast": 16.0, "k_cg_init": 8.0}      # calibration kernels
+
+
+def short(name):
+    m = re.search(r"cfd::(k_\w+(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
+def per_kernel(pattern, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for path in glob.glob(pattern, recursive=True):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = short(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return tot, cnt
+
+
+stats = {}
+spath = glob.glob(f"gpurun_out/{tag}_stats/**/*kernel_stats.csv", recursive=True)[0]
+shutil.copy(spath, f"profiles/{tag}_bench8192_kernel_stats.csv")
+for r in csv.DictReader(open(spath)):
+    stats[short(r["Name"])] = (float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+shutil.copy(f"gpurun_out/{tag}_bench.json", f"profiles/{tag}_bench8192.json")
+
+ft, fc = per_kernel(f"gpurun_out/{tag}_fetch/**/*counter_collection.csv", "FETCH_SIZE")
+wt, wc = per_kernel(f"gpurun_out/{tag}_write/**/*counter_collection.csv", "WRITE_SIZE")
+for name, (t, c) in (("FETCH_SIZE", (ft, fc)), ("WRITE_SIZE", (wt, wc))):
+    with open(f"profiles/{tag}_pmc8192_{name}_per_kernel.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "total_KB", "avg_KB_per_launch"])
+        for k in sorted(t, key=lambda k: -t[k]):
+            w.writerow([k, c[k], t[k], t[k] / c[k]])
+# calibration factor of FETCH_SIZE
+ratios = [KNOWN_READS[k] / (ft[k] / fc[k] * 1024.0 / cells) for k in KNOWN_READS if k in ft and ft[k] > 0]
+cal = sum(ratios) / len(ratios) if ratios else 2.0
+with open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv", "w", newline="") as f:
+    f.write(f"# bench.py --steps 1 --warmup 1 --no-cpu at 8192^2, one rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE), KB per launch.\n")
+    f.write(f"# WRITE_SIZE is exact for these stores. FETCH_SIZE calibrated x{cal:.3f} on the pure streaming kernels of the same run whose\n")
+    f.write(f"# read bytes are known ({', '.join(f'{k} {v:g} B/cell' for k, v in KNOWN_READS.items())}); individual factors {', '.join(f'{r:.3f}' for r in ratios)}.\n")
+    f.write(f"# avg_us / share from profiles/{tag}_bench8192_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 3).\n")
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches", "fetch_raw_B_per_cell", "fetch_calibrated_B_per_cell", "write_B_per_cell", "total_B_per_cell",
+                "algorithmic_B_per_cell", "ratio", "avg_us", "share_pct", "algorithmic_TBps"])
+    for k in sorted(ALGO, key=lambda k: -(stats.get(k, (0, 0))[1])):
+        if k not in ft or k not in stats:
+            continue
+        fr = ft[k] / fc[k] * 1024.0 / cells
+        wr = wt.get(k, 0.0) / max(wc.get(k, 1), 1) * 1024.0 / cells
+        tot = fr * cal + wr
+        us, share = stats[k]
+        w.writerow([k, fc[k], f"{fr:.2f}", f"{fr * cal:.2f}", f"{wr:.2f}", f"{tot:.2f}", ALGO[k], f"{tot / ALGO[k]:.3f}", f"{us:.1f}",
+                    f"{share:.2f}", f"{ALGO[k] * cells / us / 1e6:.2f}"])
+print(open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv").read())
