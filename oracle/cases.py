@@ -120,7 +120,7 @@ def _half_cylinder_bc(nr, nt, turbulent):
     }
 
 
-def half_cylinder(nr=12, nt=16, steps=5, turbulent=False):
+def half_cylinder(nr=12, nt=16, steps=5, turbulent=False, model="k_omega"):
     """'half_cylinder/' and 'half_cylinder_turbulent/': half annulus, i = radial,
     j = azimuthal (theta 0..pi); wall on the cylinder, outer boundary split into
     outlet (downstream half) and inlet (upstream half), symmetry on the x axis."""
@@ -130,15 +130,16 @@ def half_cylinder(nr=12, nt=16, steps=5, turbulent=False):
     turb = None
     init = {"u": 1.0, "v": 0.0, "p": 0.0}
     if turbulent:
-        turb = {"enabled": True, "model": "k_omega", "update_interval": 1}
+        turb = {"enabled": True, "model": model, "update_interval": 1}
         init["scalars"] = {"k": 1.0e-3, "omega": 5.0}
-    cfg = _base("half_cylinder_komega" if turbulent else "half_cylinder", 2.0e-2,
+    name = ("half_cylinder_sst" if model == "sst" else "half_cylinder_komega") if turbulent else "half_cylinder"
+    cfg = _base(name, 2.0e-2,
                 {"cfl": 0.5, "dt_max": 0.05, "dt_min": 0.0, "max_steps": steps},
                 _solver("simple", 3, 0.0, relax=(0.6, 0.6, 0.2)), bc, init, turbulence=turb)
     return cfg, mp, "annulus"
 
 
-def channel_komega_5x20(steps=21, tol=1.0e-8):
+def channel_komega_5x20(steps=21, tol=1.0e-8, model="k_omega"):
     """Runs/Coarse_mesh/run_test.py:25-137 (the reference's own committed run)."""
     length, height, dpdx, nu = 0.02, 0.05, -0.057, 1.5e-5
     dh = 4.0 * height
@@ -163,11 +164,11 @@ def channel_komega_5x20(steps=21, tol=1.0e-8):
                          "rho": 1.0, "use_nu_t": False, "flow_axis": "i",
                          "hydraulic_diameter": dh},
             "line_plot": {"enabled": False}}
-    cfg = _base("channel_k_omega", nu,
+    cfg = _base(f"channel_{model}", nu,
                 {"cfl": 0.5, "cfl_diff": 0.5, "dt_max": 0.1, "dt_min": 0.0, "max_steps": steps},
                 solver, bc, {"u": None, "v": 0.0, "p": 0.0,
                              "scalars": {"k": k_val, "omega": omega_val}},
-                turbulence={"enabled": True, "model": "k_omega", "update_interval": 1},
+                turbulence={"enabled": True, "model": model, "update_interval": 1},
                 forcing=(dpdx, 0.0), post=post)
     cfg["_u_ramp"] = u_bulk     # initial u = u_bulk * ramp(y), run_test.py:54-58
     return cfg, mp, "rect"
@@ -180,7 +181,7 @@ def ramp_initial_u(cfg, mesh):
     cfg["initial"]["u"] = cfg.pop("_u_ramp") * ramp
 
 
-def channel_forced(n=64, steps=3, turbulent=False, ratio_j=1.0, max_iter=2, seed=1234, tol=TIGHT):
+def channel_forced(n=64, steps=3, turbulent=False, ratio_j=1.0, max_iter=2, seed=1234, tol=TIGHT, model="k_omega"):
     """Miniature of the 8192^2 benchmark workload: periodic-i channel,
     walls, pressure-gradient forcing, perturbed parabolic initial u."""
     mp = dict(length_i=1.0, length_j=1.0, count_i=n, count_j=n, ratio_i=1.0, ratio_j=ratio_j)
@@ -194,7 +195,7 @@ def channel_forced(n=64, steps=3, turbulent=False, ratio_j=1.0, max_iter=2, seed
     turb = None
     init = {"u": None, "v": 0.0, "p": 0.0}
     if turbulent:
-        turb = {"enabled": True, "model": "k_omega", "update_interval": 1}
+        turb = {"enabled": True, "model": model, "update_interval": 1}
         init["scalars"] = {"k": 1.0e-4, "omega": 10.0}
     cfg = _base("channel_forced", 1.0e-3,
                 {"cfl": 0.5, "cfl_diff": 0.5, "dt_max": 1.0e-3, "dt_min": 0.0, "max_steps": steps},
@@ -221,4 +222,13 @@ ALL_END_TO_END = {
     "channel_komega_5x20": (lambda: channel_komega_5x20(steps=21, tol=TIGHT), ramp_initial_u),
     "channel_forced_24": (lambda: channel_forced(n=24, steps=3), perturbed_parabola),
     "channel_forced_komega_24": (lambda: channel_forced(n=24, steps=3, turbulent=True), perturbed_parabola),
+}
+
+# Menter SST variants; channel_sst_5x20 restates the second half of
+# Runs/Coarse_mesh/run_test.py (model_name = "sst", same CONFIG otherwise)
+SST_END_TO_END = {
+    "channel_sst_5x20": (lambda: channel_komega_5x20(steps=21, tol=TIGHT, model="sst"), ramp_initial_u),
+    "half_cylinder_sst": (lambda: half_cylinder(turbulent=True, model="sst"), None),
+    "channel_forced_sst_24": (lambda: channel_forced(n=24, steps=3, turbulent=True, ratio_j=1.04, model="sst"),
+                              perturbed_parabola),
 }

@@ -18,7 +18,8 @@ Three tiers, recorded in every file's `tier` entry:
      exact solve.  Tier C is cross-checked here against tier A (the committed logs of
      the real-pyamg run) before anything is written.
 
-Usage:  python oracle/gen_golden.py            (regenerates everything)
+Usage:  python oracle/gen_golden.py            (regenerates everything but the SST rows)
+        python oracle/gen_golden.py sst        (SST rows: ref_runs/sst_*, e2e_*sst*)
 """
 from __future__ import annotations
 
@@ -249,6 +250,41 @@ def selfcheck_against_committed(out):
     assert np.all(trel < 5e-6), trel
 
 
+def main_sst():
+    """SST rows only (python oracle/gen_golden.py sst): tier-A artefacts of the committed SST run,
+    tier-C runs of the authored SST cases, cross-checked against the committed SST logs."""
+    OUT.mkdir(parents=True, exist_ok=True)
+    dst = OUT / "ref_runs"
+    dst.mkdir(parents=True, exist_ok=True)
+    run = REF / "Runs" / "Coarse_mesh"
+    shutil.copyfile(run / "states" / "sst" / "fields_000000.npz", dst / "sst_fields_000000.npz")
+    for name in ("channel_sst_residual_log.txt", "channel_sst_friction_log.txt"):
+        lines = (run / "postproc" / "sst" / name).read_text().splitlines()[:201]
+        (dst / name).write_text("\n".join(lines) + "\n")
+    for q in dst.iterdir():
+        os.chmod(q, 0o644)
+    ref_solver, ref_mesh, ref_bc, ref_turb, ref_post = load_reference()
+    install_pyamg_standin()
+    try:
+        chk = run_reference_case(ref_solver, ref_mesh,
+                                 lambda: cases.channel_komega_5x20(steps=21, tol=1e-8, model="sst"),
+                                 cases.ramp_initial_u, "C")
+        txt = (run / "postproc/sst/channel_sst_residual_log.txt").read_text().splitlines()
+        committed = np.array([[float(x) for x in ln.split()] for ln in txt[1:4]])
+        hist = chk["history"]
+        mine = hist[np.isin(hist[:, 0], committed[:, 0])]
+        rel = np.abs(mine[:, 3] - committed[:, 3]) / committed[:, 3]
+        print("SST selfcheck continuity_l2 rel diff vs committed log:", rel)
+        assert np.all(rel < 5e-6), rel
+        np.savez_compressed(OUT / "e2e_channel_sst_5x20_reftol.npz", **chk)
+        for name, (builder, fixup) in cases.SST_END_TO_END.items():
+            out = run_reference_case(ref_solver, ref_mesh, builder, fixup, "C")
+            np.savez_compressed(OUT / f"e2e_{name}_frozen.npz", **out)
+            print(f"wrote e2e_{name}_frozen.npz  steps={int(out['step'])}")
+    finally:
+        remove_pyamg_standin()
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
     copy_reference_artifacts()
@@ -298,4 +334,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "sst":
+        main_sst()
+    else:
+        main()

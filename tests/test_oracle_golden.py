@@ -114,7 +114,7 @@ def test_per_function_vectors(tag):
 
 
 def _run_oracle(name, freeze):
-    builder, fixup = cases.ALL_END_TO_END[name]
+    builder, fixup = {**cases.ALL_END_TO_END, **cases.SST_END_TO_END}[name]
     cfg, mp, kind = builder()
     mesh = orc.rect_mesh(**mp) if kind == "rect" else orc.annulus_mesh(**mp)
     if fixup is not None:
@@ -125,6 +125,7 @@ def _run_oracle(name, freeze):
 E2E = [(n, "fresh") for n in ("lam_channel", "inlet_outlet_channel", "couette_piso", "half_cylinder",
                               "channel_forced_24")]
 E2E += [(n, "frozen") for n in cases.ALL_END_TO_END]
+E2E += [(n, "frozen") for n in cases.SST_END_TO_END]      # SST rows: fields include _S, _F1, _F2, _D_k, _D_omega, _d_wall
 
 
 @pytest.mark.parametrize("name,mode", E2E)
@@ -183,6 +184,35 @@ def test_committed_run_logs_and_state():
         assert abs(r["friction"]["bulk_velocity"] - frow[5]) <= 2e-6 * abs(frow[5])
     st = load_golden("ref_runs/k_omega_fields_000000.npz")
     for k in ("u", "k", "omega", "nu_t"):
+        assert rel_l2(mask_corners(snap[k]), mask_corners(st[k])) < 1e-7, k
+    for k in ("v", "p"):
+        assert np.max(np.abs(mask_corners(snap[k]) - mask_corners(st[k]))) < 1e-9, k
+
+
+def test_committed_sst_run_logs_and_state():
+    """Tier A for the SST model: the reference's committed 5x20 SST run (real pyamg, rtol 1e-8):
+    residual / friction logs lines 2-4 and states/sst/fields_000000.npz incl. the cached SST planes."""
+    cfg, mp, _ = cases.channel_komega_5x20(steps=21, tol=1e-8, model="sst")
+    mesh = orc.rect_mesh(**mp)
+    cases.ramp_initial_u(cfg, mesh)
+    snap = {}
+
+    def grab(fields, rec):
+        if rec["step"] == 0:
+            snap.update({k: v.copy() for k, v in fields.items()})
+
+    _, _, _, hist = orc.run_case(cfg, mesh, solver_mode="direct", freeze_pressure=True, on_step=grab)
+    res = np.loadtxt(GOLDEN / "ref_runs" / "channel_sst_residual_log.txt", skiprows=1)[:3]
+    fric = np.loadtxt(GOLDEN / "ref_runs" / "channel_sst_friction_log.txt", skiprows=1)[:3]
+    by_step = {r["step"]: r for r in hist}
+    for row, frow in zip(res, fric):
+        r = by_step[int(row[0])]
+        assert r["inner"] == int(row[2])
+        assert abs(r["time"] - row[1]) <= 2e-6 * max(row[1], 1e-30)
+        assert abs(r["cont"] - row[3]) <= 2e-6 * row[3]
+        assert abs(4.0 * r["friction"]["cf"] - frow[2]) <= 2e-6 * abs(frow[2])
+    st = load_golden("ref_runs/sst_fields_000000.npz")
+    for k in ("u", "k", "omega", "nu_t", "_S", "_F1", "_F2", "_D_k", "_D_omega", "_d_wall"):
         assert rel_l2(mask_corners(snap[k]), mask_corners(st[k])) < 1e-7, k
     for k in ("v", "p"):
         assert np.max(np.abs(mask_corners(snap[k]) - mask_corners(st[k]))) < 1e-9, k
