@@ -15,12 +15,17 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("CFD_HIP_LIB", _HERE / "libcfd_hip.so"))
 
 F_U, F_V, F_P, F_K, F_OMEGA, F_NUT, F_PCORR, F_AP, F_AI, F_AJ, F_BU, F_BV = range(12)
+F_SST_S, F_SST_F1, F_SST_F2, F_SST_DK, F_SST_DW, F_SST_DWALL = range(12, 18)
+TURB_KOMEGA, TURB_SST = 0, 1
 KIND_GHOSTED, KIND_CELL, KIND_FACE_I, KIND_FACE_J = range(4)
 SIDE_IMIN, SIDE_IMAX, SIDE_JMIN, SIDE_JMAX = range(4)
 SIDES = {"i_min": 0, "i_max": 1, "j_min": 2, "j_max": 3}
 BC_NONE, BC_AFFINE, BC_SYMMETRY, BC_PERIODIC = range(4)
 TOP_WRAP_I, TOP_WRAP_J, TOP_SET_INTERIOR, TOP_AFFINE_GHOST = range(4)
 FIELD_IDS = {"u": F_U, "v": F_V, "p": F_P, "k": F_K, "omega": F_OMEGA, "nu_t": F_NUT, "p_corr": F_PCORR}
+# the SST caches the reference keeps inside `fields` (turbulence.py:447-534, 343-355)
+SST_FIELD_IDS = {"_S": F_SST_S, "_F1": F_SST_F1, "_F2": F_SST_F2, "_D_k": F_SST_DK, "_D_omega": F_SST_DW,
+                 "_d_wall": F_SST_DWALL}
 
 
 class TurbOp(C.Structure):
@@ -65,6 +70,11 @@ SIGNATURES = {
     "cfd_set_transport_solver": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int]),
     "cfd_set_smoother_omega2": (C.c_int, [_vp, C.c_double]),
     "cfd_set_flux_kernels": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "cfd_set_turbulence_model": (C.c_int, [_vp, C.c_int]),
+    "cfd_upload_cell_centers": (C.c_int, [_vp, _dp]),
+    "cfd_set_wall_faces": (C.c_int, [_vp, C.c_int, _dp]),
+    "cfd_sst_get_cached": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "cfd_sst_set_cached": (C.c_int, [_vp, C.c_int]),
     "cfd_set_turbulence_clip": (C.c_int, [_vp, C.c_double, C.c_double]),
     "cfd_set_flow_bc": (C.c_int, [_vp, C.c_int, C.c_int, _ip, _ip] + [_dp] * 8),
     "cfd_set_periodicity": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),

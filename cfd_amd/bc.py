@@ -128,6 +128,33 @@ class BoundaryGeometry:
                     "j_min": grid(x, y[0:2]), "j_max": grid(x, y[-2:])})
 
 
+def wall_face_centers(node, bc_cfg):
+    """Face centres (M, 2) of all boundary faces of type "wall", segment after segment
+    (turbulence._wall_face_centers / _compute_wall_distance, turbulence.py:69-121)."""
+    node = np.asarray(node, dtype=float)
+    count_i, count_j = node.shape[0] - 1, node.shape[1] - 1
+    out = []
+    for boundary, segments in bc_cfg.items():
+        if boundary == "pressure_reference" or segments is None:
+            continue
+        for seg in _normalize_segments(segments):
+            if seg.get("type") != "wall":
+                continue
+            rng = seg.get("range")
+            if boundary in ("i_min", "i_max"):
+                start, end = (0, count_j - 1) if rng is None else rng
+                col = 0 if boundary == "i_min" else count_i
+                n0, n1 = node[col, start:end + 1, :], node[col, start + 1:end + 2, :]
+            else:
+                start, end = (0, count_i - 1) if rng is None else rng
+                row = 0 if boundary == "j_min" else count_j
+                n0, n1 = node[start:end + 1, row, :], node[start + 1:end + 2, row, :]
+            out.append(0.5 * (n0 + n1))
+    if not out:
+        return np.zeros((0, 2))
+    return np.ascontiguousarray(np.concatenate(out, axis=0))
+
+
 def _expand(value, n):
     """bc.py:123-130."""
     if np.isscalar(value):

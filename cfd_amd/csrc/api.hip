@@ -325,6 +325,8 @@ int cfd_destroy(cfd_ctx *ctx) {
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->own_ws && c->ws) hipFree(c->ws);
+    if (c->sst_mem) hipFree(c->sst_mem);
+    if (c->wall_xy) hipFree(c->wall_xy);
     delete ctx;
     return CFD_OK;
 }
@@ -373,6 +375,12 @@ static double *field_plane(Ctx *c, int id) {
         case CFD_F_AJ: return c->aj;
         case CFD_F_BU: return c->bu;
         case CFD_F_BV: return c->bv;
+        case CFD_F_SST_S: return c->sst_S;
+        case CFD_F_SST_F1: return c->sst_F1;
+        case CFD_F_SST_F2: return c->sst_F2;
+        case CFD_F_SST_DK: return c->sst_Dk;
+        case CFD_F_SST_DW: return c->sst_Dw;
+        case CFD_F_SST_DWALL: return c->sst_dw;
         default: return nullptr;
     }
 }
@@ -477,6 +485,7 @@ int cfd_upload_field(cfd_ctx *ctx, int field_id, const double *host, int kind) {
     if (!pl || !host || kind < 0 || kind > 3) { set_error("cfd_upload_field: bad arguments"); return CFD_E_ARG; }
     CFD_TRY(to_device(c, host, pl, kind));
     if (field_id == CFD_F_NUT || field_id == CFD_F_AP || field_id == CFD_F_AI || field_id == CFD_F_AJ) c->ap_cached = false;
+    if (field_id == CFD_F_SST_DWALL) c->sst_dw_set = true;
     // u, v, p exist twice (ping-pong): keep never-written ghosts (corners) identical in both
     if (field_id == CFD_F_U) CFD_TRY(launch_copy_plane(c, pl, c->U1()));
     if (field_id == CFD_F_V) CFD_TRY(launch_copy_plane(c, pl, c->V1()));
@@ -829,12 +838,110 @@ int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, dou
     return finish_iteration(c, dt, &res[0]);
 }
 
+// update_turbulence with the Menter SST closure (solver.py:1090-1153 + turbulence.py:343-355, 447-566).
+// k and omega have different blended diffusivities, hence two operators and two single-RHS solves.
+static int sst_step(Ctx *c, double dt) {
+    if (!c->cc_set) { set_error("SST needs the cell centres (cfd_upload_cell_centers)"); return CFD_E_STATE; }
+    CFD_TRY(launch_turb_bc(c));
+    if (!c->sst_dw_set) {                       // _d_wall is computed once (turbulence.py:345-346)
+        CFD_TRY(launch_wall_distance(c));
+        c->sst_dw_set = true;
+    }
+    CFD_TRY(launch_sst_f2_full(c));             // tail of apply_bcs: fresh _F2 on the whole planes
+    CFD_TRY(launch_eddy_viscosity(c));          // limiter with the _S of the PREVIOUS update (none in the first)
+    CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+    c->dt_ap = dt;
+    double *sk = c->kry[13], *sw = c->kry[14];
+    CFD_TRY(launch_sst_sources(c));             // _S, _F1, _F2, _D_k, _D_omega + adv + source of k, omega
+    c->sst_cached = true;
+    CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ti, c->tj, c->tp, c->sst_Dk));
+    CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->wi, c->wj, c->wp, c->sst_Dw));
+    CFD_TRY(launch_sst_rhs(c, dt, c->k, sk, c->ti, c->tj, c->bu));
+    CFD_TRY(launch_sst_rhs(c, dt, c->omega, sw, c->wi, c->wj, c->bv));
+    int its[2] = {0, 0};
+    for (int q = 0; q < 2; ++q) {
+        const OpDev op = q == 0 ? OpDev{c->ti, c->tj, c->tp, c->g, c->per_i, c->per_j}
+                                : OpDev{c->wi, c->wj, c->wp, c->g, c->per_i, c->per_j};
+        double *b[2] = {q == 0 ? c->bu : c->bv, nullptr}, *x[2] = {q == 0 ? c->k : c->omega, nullptr};
+        const double *x0[2] = {x[0], nullptr};
+        double rel[2] = {0, 0};
+        CFD_TRY(momentum_like_solve(c, op, b, x, c->warm_start ? x0 : nullptr, 1, c->turb_tol, c->turb_maxiter, &its[q], rel,
+                                    nullptr));
+        c->stats.k_relres[q] = rel[0];
+    }
+    c->stats.k_iters = its[0] > its[1] ? its[0] : its[1];
+    c->stats.k_solver = c->stats_last_solver;
+    CFD_TRY(launch_clip(c, c->k, c->k_clip));
+    CFD_TRY(launch_clip(c, c->omega, c->omega_clip));
+    CFD_TRY(launch_turb_bc(c));
+    return launch_sst_f2_full(c);
+}
+
+int cfd_set_turbulence_model(cfd_ctx *ctx, int model) {
+    CTX_MUT(ctx);
+    if (model != CFD_TURB_KOMEGA && model != CFD_TURB_SST) { set_error("unknown turbulence model %d", model); return CFD_E_ARG; }
+    if (model == CFD_TURB_SST) {
+        if (c->comm.nranks > 1) { set_error("the SST closure is single-rank only"); return CFD_E_STATE; }
+        if (!c->sst_mem) {
+            const size_t pb = c->g.plane_elems() * sizeof(double);
+            CFD_HIP(hipMalloc((void **)&c->sst_mem, 11 * pb));
+            CFD_HIP(hipMemsetAsync(c->sst_mem, 0, 11 * pb, c->stream));
+            double **pl[11] = {&c->sst_S, &c->sst_F1, &c->sst_F2, &c->sst_Dk, &c->sst_Dw, &c->sst_dw, &c->m_xc, &c->m_yc,
+                               &c->wp, &c->wi, &c->wj};
+            for (int q = 0; q < 11; ++q) *pl[q] = (double *)(c->sst_mem + (size_t)q * pb);
+            CFD_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    c->turb_model = model;
+    c->ap_cached = false;
+    return CFD_OK;
+}
+
+int cfd_upload_cell_centers(cfd_ctx *ctx, const double *cell_center) {
+    CTX_MUT(ctx);
+    if (!cell_center) { set_error("cfd_upload_cell_centers: null"); return CFD_E_ARG; }
+    if (!c->sst_mem) { set_error("cfd_upload_cell_centers: select the SST closure first"); return CFD_E_STATE; }
+    double *pl[2] = {c->m_xc, c->m_yc};
+    CFD_TRY(to_device_comp(c, cell_center, 2, pl, CFD_KIND_CELL));
+    c->cc_set = true;
+    c->sst_dw_set = false;
+    return CFD_OK;
+}
+
+int cfd_set_wall_faces(cfd_ctx *ctx, int n, const double *xy) {
+    CTX_MUT(ctx);
+    if (n < 0 || (n > 0 && !xy)) { set_error("cfd_set_wall_faces: bad arguments"); return CFD_E_ARG; }
+    if (c->wall_xy) { CFD_HIP(hipFree(c->wall_xy)); c->wall_xy = nullptr; }
+    c->n_wall = n;
+    if (n > 0) {
+        CFD_HIP(hipMalloc((void **)&c->wall_xy, (size_t)n * 2 * sizeof(double)));
+        CFD_HIP(hipMemcpy(c->wall_xy, xy, (size_t)n * 2 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->sst_dw_set = false;
+    return CFD_OK;
+}
+
+int cfd_sst_get_cached(cfd_ctx *ctx, int *cached) {
+    CTX(ctx);
+    if (!cached) return CFD_E_ARG;
+    *cached = c->sst_cached ? 1 : 0;
+    return CFD_OK;
+}
+
+int cfd_sst_set_cached(cfd_ctx *ctx, int cached) {
+    CTX_MUT(ctx);
+    if (cached && !c->sst_mem) { set_error("cfd_sst_set_cached: select the SST closure first"); return CFD_E_STATE; }
+    c->sst_cached = cached != 0;
+    return CFD_OK;
+}
+
 int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
     CTX_MUT(ctx);
     CFD_TRY(ready(c));
     if (!c->turbulent) { set_error("turbulence is disabled"); return CFD_E_STATE; }
     Phase ph(c, PH_TURB);
     c->ap_cached = false;
+    if (c->turb_model == CFD_TURB_SST) return sst_step(c, dt);
     CFD_TRY(launch_turb_bc(c));
     // wall BCs also overwrite interior cells (turbulence.py:304-311): the neighbours' halo rows follow
     CFD_TRY(halo_exchange(c, c->g, 1, c->k, c->omega));

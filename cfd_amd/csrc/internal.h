@@ -204,6 +204,17 @@ struct Ctx {
     double rhs_dt = -1.0;
     int rhs_cur = -1;
     double k_clip = 1e-10, omega_clip = 1e-10;
+    // Menter SST (turbulence.py:41-208, 343-355, 447-534); planes live in one allocation of their own
+    // (sst_mem, made by cfd_set_turbulence_model) so that k-omega and laminar runs do not pay for them
+    int turb_model = 0;           // CFD_TURB_KOMEGA / CFD_TURB_SST
+    char *sst_mem = nullptr;
+    double *sst_S = nullptr, *sst_F1 = nullptr, *sst_F2 = nullptr, *sst_Dk = nullptr, *sst_Dw = nullptr, *sst_dw = nullptr;
+    double *m_xc = nullptr, *m_yc = nullptr;     // cell centres
+    double *wp = nullptr, *wi = nullptr, *wj = nullptr;   // omega transport operator (k keeps tp, ti, tj)
+    double *wall_xy = nullptr;    // wall face centres (x, y) pairs
+    int n_wall = 0;
+    bool sst_cached = false;      // _S, _F1, _F2, _D_k, _D_omega, _d_wall exist (after the first update / a restart)
+    bool sst_dw_set = false, cc_set = false;
     double dt_ap = -1.0;          // dt the a_P plane was built with
     bool ap_cached = false;       // laminar: a_P / a_i / a_j are current for dt_ap
     double rho_cached = -1.0;     // Jacobi row-sum bound of the cached momentum operator (< 0: unknown)
@@ -243,7 +254,12 @@ inline dim3 grid2d(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4, 1
 
 // stencil.hip
 int launch_eddy_viscosity(Ctx *c);
-int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap);
+int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap,
+                        const double *nu_plane = nullptr);
+int launch_wall_distance(Ctx *c);
+int launch_sst_f2_full(Ctx *c);
+int launch_sst_sources(Ctx *c);
+int launch_sst_rhs(Ctx *c, double dt, const double *phi, const double *src, const double *ci, const double *cj, double *b);
 int launch_flow_bc(Ctx *c, double *u, double *v, double *p);
 int launch_turb_bc(Ctx *c);
 int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]);

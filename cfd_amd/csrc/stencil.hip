@@ -118,7 +118,10 @@ __device__ __forceinline__ double upwind(const double *phi, size_t c, int pitch,
 // ----------------------------------------------------------------------------------
 // eddy viscosity (turbulence.py:388-394): whole ghosted plane, corners included
 // ----------------------------------------------------------------------------------
-__global__ void k_eddy_viscosity(Geo g, const double *k, const double *om, double *nut, int turbulent) {
+constexpr double SST_A1 = 0.31;
+// sst: 0 = k-omega; 1 = SST before _S exists (a1 k / omega, turbulence.py:382-384); 2 = SST limiter
+__global__ void k_eddy_viscosity(Geo g, const double *k, const double *om, double *nut, int turbulent, int sst,
+                                 const double *S, const double *F2) {
     const int ig = blockIdx.x * 64 + threadIdx.x, jg = blockIdx.y * 4 + threadIdx.y;
     if (ig > g.ni + 1 || jg > g.nj + 1) return;
     const size_t c = g.at(ig, jg);
@@ -127,12 +130,18 @@ __global__ void k_eddy_viscosity(Geo g, const double *k, const double *om, doubl
         return;
     }
     const double ks = fmax(k[c], K_FLOOR), os = fmax(om[c], OMEGA_FLOOR);
-    nut[c] = 1.0 * ks / os;
+    if (sst == 0) {
+        nut[c] = 1.0 * ks / os;
+    } else {
+        const double denom = sst == 2 ? fmax(SST_A1 * os, S[c] * F2[c]) : os;
+        nut[c] = fmax(SST_A1 * ks / denom, 0.0);
+    }
 }
 
 int launch_eddy_viscosity(Ctx *c) {
+    const int sst = c->turb_model == CFD_TURB_SST ? (c->sst_cached ? 2 : 1) : 0;
     hipLaunchKernelGGL(k_eddy_viscosity, grid2d(c->g.ni + 2, c->g.nj + 2), block2d(), 0, c->stream, c->g, c->k,
-                       c->omega, c->nut, c->turbulent);
+                       c->omega, c->nut, c->turbulent, sst, c->sst_S, c->sst_F2);
     CFD_HIP(hipGetLastError());
     return CFD_OK;
 }
@@ -141,6 +150,8 @@ int launch_eddy_viscosity(Ctx *c) {
 // face diffusion conductances + momentum diagonal (solver.py:147-230, 439-452)
 // nu_cell = nu + coef * nu_t.  Writes a_i (west faces + the i_max face), a_j, a_P.
 // ----------------------------------------------------------------------------------
+// nut may be any cell plane: nu = 0, coef = 1 gives nu_cell = the plane itself, bit for bit (SST
+// blended diffusivities _D_k, _D_omega)
 __global__ void k_diffusion_ap(Geo g, MeshDev m, const double *nut, double nu, double coef, double inv_dt, double *ai,
                                double *aj, double *ap) {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
@@ -183,9 +194,9 @@ __global__ void k_diffusion_ap(Geo g, MeshDev m, const double *nut, double nu, d
     ap[c] = m.vol[c] * inv_dt + aw + ae + as + an;
 }
 
-int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap) {
-    hipLaunchKernelGGL(k_diffusion_ap, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->nut,
-                       c->nu, nut_coef, 1.0 / dt, ai, aj, ap);
+int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap, const double *nu_plane) {
+    hipLaunchKernelGGL(k_diffusion_ap, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(),
+                       nu_plane ? nu_plane : c->nut, nu_plane ? 0.0 : c->nu, nu_plane ? 1.0 : nut_coef, 1.0 / dt, ai, aj, ap);
     CFD_HIP(hipGetLastError());
     return CFD_OK;
 }
@@ -196,7 +207,7 @@ int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *
 // segments (last one wins) into per-index tables.
 // ----------------------------------------------------------------------------------
 struct WrapList {
-    double *p[8];
+    double *p[12];
     int n;
 };
 
@@ -249,6 +260,10 @@ int launch_flow_bc(Ctx *c, double *u, double *v, double *p) {
         wl.p[wl.n++] = c->omega;
     }
     wl.p[wl.n++] = c->nut;
+    if (c->turb_model == CFD_TURB_SST && c->sst_cached) {
+        // the reference keeps its SST caches inside `fields`, so the periodic copy wraps them too (bc.py:94-120)
+        for (double *q : {c->sst_S, c->sst_F1, c->sst_F2, c->sst_Dk, c->sst_Dw, c->sst_dw}) wl.p[wl.n++] = q;
+    }
     const int n = c->g.ni > c->g.nj ? c->g.ni : c->g.nj;
     hipLaunchKernelGGL(k_flow_bc, dim3((n + 255) / 256, 4, 1), dim3(256, 1, 1), 0, c->stream, c->g, c->fbc, u, v, p, wl,
                        c->wrap_p_i, c->wrap_p_j);
@@ -961,6 +976,185 @@ int launch_weighted_sum(Ctx *c, const double *f, const double *w, double out[2])
     c->n_red_blocks = nb;
     CFD_TRY(reduce_finish(c, 2, 0));
     return read_scalars(c, 0, 2, out);
+}
+
+// ----------------------------------------------------------------------------------
+// Menter SST (turbulence.py:41-208, 343-355, 447-534)
+// ----------------------------------------------------------------------------------
+constexpr double SST_SIGMA_K1 = 0.85, SST_SIGMA_K2 = 1.0, SST_SIGMA_W1 = 0.5, SST_SIGMA_W2 = 0.856;
+constexpr double SST_BETA1 = 0.075, SST_BETA2 = 0.0828, SST_GAMMA1 = 5.0 / 9.0, SST_GAMMA2 = 0.44, SST_BETA_STAR = 0.09;
+
+__device__ __forceinline__ double sst_f2(double k, double om, double d, double nu) {     // turbulence.py:143-155
+    const double sk = sqrt(fmax(k, 0.0));
+    const double t1 = 2.0 * sk / (SST_BETA_STAR * om * d);
+    const double t2 = 500.0 * nu / (d * d * om);
+    const double a = fmax(t1, t2);
+    return tanh(a * a);
+}
+
+// wall distance: min over all wall FACE CENTRES (brute force like turbulence.py:96-136), 1.0 without walls
+__global__ void k_wall_distance(Geo g, const double *xc, const double *yc, const double *wall_xy, int n_wall, double *dw) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    __shared__ double sx[256], sy[256];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const bool in = i < g.ni && j < g.nj;
+    const size_t c = in ? g.cell(i, j) : 0;
+    const double x = in ? xc[c] : 0.0, y = in ? yc[c] : 0.0;
+    double d = INFINITY;
+    for (int base = 0; base < n_wall; base += 256) {
+        __syncthreads();
+        if (base + tid < n_wall) { sx[tid] = wall_xy[2 * (base + tid)]; sy[tid] = wall_xy[2 * (base + tid) + 1]; }
+        __syncthreads();
+        const int n = min(256, n_wall - base);
+        for (int q = 0; q < n; ++q) d = fmin(d, hypot(x - sx[q], y - sy[q]));
+    }
+    if (!in) return;
+    if (isinf(d)) d = 1.0;
+    dw[c] = fmax(d, 1.0e-12);
+}
+
+// ghosts of up to 6 cell planes = nearest interior cell (edges: adjacent cell, corners: the interior
+// corner cell; turbulence.py:127-135, 469-473, 500-505, 515-521)
+struct Planes6 {
+    double *p[6];
+    int n;
+};
+__global__ void k_ghost_extend(Geo g, Planes6 pl) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 2 * (g.ni + 2) + 2 * g.nj;
+    if (t >= per) return;
+    int ig, jg;
+    if (t < g.ni + 2) { ig = t; jg = 0; }
+    else if (t < 2 * (g.ni + 2)) { ig = t - (g.ni + 2); jg = g.nj + 1; }
+    else if (t < 2 * (g.ni + 2) + g.nj) { ig = 0; jg = t - 2 * (g.ni + 2) + 1; }
+    else { ig = g.ni + 1; jg = t - 2 * (g.ni + 2) - g.nj + 1; }
+    const int is = min(max(ig, 1), g.ni), js = min(max(jg, 1), g.nj);
+    for (int q = 0; q < pl.n; ++q) pl.p[q][g.at(ig, jg)] = pl.p[q][g.at(is, js)];
+}
+static int launch_ghost_extend(Ctx *c, std::initializer_list<double *> planes) {
+    Planes6 pl{};
+    for (double *q : planes) pl.p[pl.n++] = q;
+    const int per = 2 * (c->g.ni + 2) + 2 * c->g.nj;
+    hipLaunchKernelGGL(k_ghost_extend, dim3((per + 255) / 256), dim3(256), 0, c->stream, c->g, pl);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+int launch_wall_distance(Ctx *c) {
+    hipLaunchKernelGGL(k_wall_distance, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->m_xc, c->m_yc, c->wall_xy,
+                       c->n_wall, c->sst_dw);
+    CFD_HIP(hipGetLastError());
+    return launch_ghost_extend(c, {c->sst_dw});
+}
+
+// _F2 on the whole ghosted planes, corners included (tail of turbulence.apply_bcs, 343-355)
+__global__ void k_sst_f2_full(Geo g, const double *k, const double *om, const double *dw, double nu, double *F2) {
+    const int ig = blockIdx.x * 64 + threadIdx.x, jg = blockIdx.y * 4 + threadIdx.y;
+    if (ig > g.ni + 1 || jg > g.nj + 1) return;
+    const size_t c = g.at(ig, jg);
+    F2[c] = sst_f2(fmax(k[c], K_FLOOR), fmax(om[c], OMEGA_FLOOR), fmax(dw[c], 1.0e-12), nu);
+}
+int launch_sst_f2_full(Ctx *c) {
+    hipLaunchKernelGGL(k_sst_f2_full, grid2d(c->g.ni + 2, c->g.nj + 2), block2d(), 0, c->stream, c->g, c->k, c->omega, c->sst_dw,
+                       c->nu, c->sst_F2);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// Sources of the SST k / omega equations (turbulence.py:447-534) fused with the upwind advection of k and
+// omega (solver.py:1109-1121): writes the interior of _S, _F1, _F2, _D_k, _D_omega and
+// sk = adv(k) + source_k, sw = adv(omega) + source_omega.
+struct SstOut {
+    double *S, *F1, *F2, *Dk, *Dw, *sk, *sw;
+};
+__global__ void k_sst_sources(Geo g, MeshDev m, FluxIn f, const double *om, const double *nut, const double *dwall, const double *xc,
+                              const double *yc, double nu, SstOut o) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    const double fw = flux_i(f, m, c, i == 0, false), fe = flux_i(f, m, c + 1, false, i == g.ni - 1);
+    const double fs = flux_j(f, m, c, P, g.blo(j), false), fn = flux_j(f, m, c + P, P, false, g.bhi(j));
+    const double vol = m.vol[c];
+    const double *kk = f.k;
+    const double advk = upwind(kk, c, P, fw, fe, fs, fn, vol);
+    const double advw = upwind(om, c, P, fw, fe, fs, fn, vol);
+    double ux, uy, vx, vy;
+    const double *uu = f.u, *vv = f.v;
+    green_gauss([uu](size_t q) { return uu[q]; }, m, c, P, ux, uy);
+    green_gauss([vv](size_t q) { return vv[q]; }, m, c, P, vx, vy);
+    const double s2 = 2.0 * (ux * ux) + 2.0 * (vy * vy) + (uy + vx) * (uy + vx);
+    const double smag = sqrt(fmax(s2, 0.0));
+    const double k = fmax(kk[c], K_FLOOR), w = fmax(om[c], OMEGA_FLOOR), nt = nut[c];
+    const double d = fmax(dwall[c], 1.0e-12);
+    // central differences over the cell-centre spacing (turbulence.py:179-208)
+    double dx, dy;
+    if (i > 0 && i < g.ni - 1) dx = xc[c + 1] - xc[c - 1];
+    else if (i == 0) dx = 2.0 * (xc[c + 1] - xc[c]);
+    else dx = 2.0 * (xc[c] - xc[c - 1]);
+    if (fabs(dx) < 1.0e-15) dx = 1.0;
+    if (j > 0 && j < g.nj - 1) dy = yc[c + P] - yc[c - P];
+    else if (j == 0) dy = 2.0 * (yc[c + P] - yc[c]);
+    else dy = 2.0 * (yc[c] - yc[c - P]);
+    if (fabs(dy) < 1.0e-15) dy = 1.0;
+    const double kx = (kk[c + 1] - kk[c - 1]) / dx, ky = (kk[c + P] - kk[c - P]) / dy;
+    const double wx = (om[c + 1] - om[c - 1]) / dx, wy = (om[c + P] - om[c - P]) / dy;
+    const double cross = kx * wx + ky * wy;
+    const double cd = fmax(2.0 * SST_SIGMA_W2 / w * cross, 1.0e-20);
+    // blending functions (turbulence.py:143-172)
+    const double sk = sqrt(fmax(k, 0.0));
+    const double t1 = sk / (SST_BETA_STAR * w * d);
+    const double t2 = 500.0 * nu / (d * d * w);
+    const double t3 = 4.0 * SST_SIGMA_W2 * k / (cd * d * d);
+    const double a1 = fmin(fmax(t1, t2), t3);
+    const double F1 = tanh(pow(a1, 4.0));
+    const double F2 = sst_f2(k, w, d, nu);
+    const double sig_k = F1 * SST_SIGMA_K1 + (1.0 - F1) * SST_SIGMA_K2;
+    const double sig_w = F1 * SST_SIGMA_W1 + (1.0 - F1) * SST_SIGMA_W2;
+    const double beta = F1 * SST_BETA1 + (1.0 - F1) * SST_BETA2;
+    const double gamma = F1 * SST_GAMMA1 + (1.0 - F1) * SST_GAMMA2;
+    o.S[c] = smag; o.F1[c] = F1; o.F2[c] = F2;
+    o.Dk[c] = nu + sig_k * nt;
+    o.Dw[c] = nu + sig_w * nt;
+    const double pk = fmin(nt * s2, 20.0 * SST_BETA_STAR * k * w);
+    const double srck = pk - SST_BETA_STAR * k * w;
+    const double srcw = gamma * s2 - beta * (w * w) + 2.0 * (1.0 - F1) * SST_SIGMA_W2 / w * cross;
+    o.sk[c] = advk + srck;
+    o.sw[c] = advw + srcw;
+}
+int launch_sst_sources(Ctx *c) {
+    FluxIn f{c->U(), c->V(), c->P(), c->k, c->ap, c->rhie_chow};
+    SstOut o{c->sst_S, c->sst_F1, c->sst_F2, c->sst_Dk, c->sst_Dw, c->kry[13], c->kry[14]};
+    hipLaunchKernelGGL(k_sst_sources, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, c->omega, c->nut,
+                       c->sst_dw, c->m_xc, c->m_yc, c->nu, o);
+    CFD_HIP(hipGetLastError());
+    return launch_ghost_extend(c, {c->sst_S, c->sst_F1, c->sst_F2, c->sst_Dk, c->sst_Dw});
+}
+
+// b = V/dt phi + V src + boundary terms with the scalar's own face conductances (solver.py:723-730)
+__global__ void k_sst_rhs(Geo g, const double *vol, const double *phi, const double *src, const double *ci, const double *cj,
+                          double inv_dt, int per_i, int per_j, double *b) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    const double v = vol[c];
+    double r = v * inv_dt * phi[c] + v * src[c];
+    if (!per_i) {
+        if (i == 0) r += ci[c] * phi[c - 1];
+        if (i == g.ni - 1) r += ci[c + 1] * phi[c + 1];
+    }
+    if (!per_j) {
+        if (g.blo(j)) r += cj[c] * phi[c - P];
+        if (g.bhi(j)) r += cj[c + P] * phi[c + P];
+    }
+    b[c] = r;
+}
+int launch_sst_rhs(Ctx *c, double dt, const double *phi, const double *src, const double *ci, const double *cj, double *b) {
+    hipLaunchKernelGGL(k_sst_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->m_vol, phi, src, ci, cj, 1.0 / dt,
+                       c->per_i, c->per_j, b);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
 }
 
 // ----------------------------------------------------------------------------------

@@ -132,13 +132,47 @@ class Device:
         for name, fid in _lib.FIELD_IDS.items():
             if name in fields and name != "p_corr":
                 self.upload(fid, fields[name])
+        if getattr(self, "sst", False) and all(name in fields for name in _lib.SST_FIELD_IDS):
+            # a restart state of an SST run carries the caches (solver.py:1296-1310 saves every entry of fields)
+            for name, fid in _lib.SST_FIELD_IDS.items():
+                self.upload(fid, fields[name])
+            check(self.lib.cfd_sst_set_cached(self._h, 1))
 
     def download_fields(self, fields):
         """Refresh the host dict in place (arrays are caller visible, solver.py:333)."""
         for name, fid in _lib.FIELD_IDS.items():
             if name in fields:
                 self.download(fid, out=fields[name], whole=True)
+        if getattr(self, "sst", False) and self.sst_cached():
+            # the reference's SST caches live inside `fields` (turbulence.py:473, 505, 521, 346)
+            for name, fid in _lib.SST_FIELD_IDS.items():
+                if name not in fields:
+                    fields[name] = np.empty(self.shape(_lib.KIND_GHOSTED, whole=True))
+                self.download(fid, out=fields[name], whole=True)
         return fields
+
+    # ---------------------------------------------------------------- Menter SST
+    def set_turbulence_model(self, model, mesh=None, bc_cfg=None):
+        """model: "k_omega" | "sst".  SST needs mesh["cell_center"], mesh["node"] and the boundary config
+        (wall face centres, turbulence.py:69-93)."""
+        self.sst = model == "sst"
+        check(self.lib.cfd_set_turbulence_model(self._h, _lib.TURB_SST if self.sst else _lib.TURB_KOMEGA))
+        if not self.sst:
+            return
+        if mesh is None or bc_cfg is None:
+            raise ValueError("the SST closure needs the mesh (cell_center, node) and the boundary config")
+        cc = _f64(mesh["cell_center"])
+        if cc.shape != (self.ni, self.nj, 2):
+            raise ValueError(f"cell_center is {cc.shape}, context is {(self.ni, self.nj, 2)}")
+        check(self.lib.cfd_upload_cell_centers(self._h, dptr(cc)))
+        from .bc import wall_face_centers
+        xy = _f64(wall_face_centers(mesh["node"], bc_cfg))
+        check(self.lib.cfd_set_wall_faces(self._h, int(xy.shape[0]), dptr(xy) if xy.shape[0] else None))
+
+    def sst_cached(self):
+        out = C.c_int(0)
+        check(self.lib.cfd_sst_get_cached(self._h, C.byref(out)))
+        return bool(out.value)
 
     # ---------------------------------------------------------------- parameters
     def set_physics(self, nu, pressure_gradient=(0.0, 0.0), rhie_chow=True, turbulent=False):

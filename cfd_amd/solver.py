@@ -233,8 +233,6 @@ def _validate_turbulence(fields, turb_cfg, bc_cfg):
     model = turb_cfg.get("model")
     if model not in ("k_omega", "sst"):
         raise NotImplementedError(f"Unknown turbulence model: {model}")
-    if model == "sst":
-        raise NotImplementedError("the MI355X build covers the k_omega model; 'sst' is not in scope yet")
     for boundary, segments in bc_cfg.items():
         if boundary == "pressure_reference" or segments is None:
             continue
@@ -449,6 +447,8 @@ def run_case(config):
     try:
         dev.upload_mesh(mesh)
         configure_device(dev, config, BoundaryGeometry.from_nodes(mesh["node"]), nu, turb_on)
+        if turb_on:
+            dev.set_turbulence_model(turb_cfg.get("model"), mesh, config["boundary"])
         dev.upload_fields(fields)
         if timing_enabled:
             dev.enable_phase_timing(True)

@@ -40,7 +40,13 @@ enum {
 /* field ids for upload / download (fields dict of solver.py:370-387, turbulence.py:215-259) */
 enum { CFD_F_U = 0, CFD_F_V = 1, CFD_F_P = 2, CFD_F_K = 3, CFD_F_OMEGA = 4, CFD_F_NUT = 5,
        CFD_F_PCORR = 6, CFD_F_AP = 7, CFD_F_AI = 8, CFD_F_AJ = 9, CFD_F_BU = 10, CFD_F_BV = 11,
-       CFD_F_COUNT = 12 };
+       /* Menter SST caches the reference keeps inside `fields` (turbulence.py:447-534, 343-355): _S, _F1, _F2,
+        * _D_k, _D_omega, _d_wall; valid ids only after cfd_set_turbulence_model(ctx, CFD_TURB_SST)          */
+       CFD_F_SST_S = 12, CFD_F_SST_F1 = 13, CFD_F_SST_F2 = 14, CFD_F_SST_DK = 15, CFD_F_SST_DW = 16, CFD_F_SST_DWALL = 17,
+       CFD_F_COUNT = 18 };
+
+/* turbulence closures (turbulence.py:19-62) */
+enum { CFD_TURB_KOMEGA = 0, CFD_TURB_SST = 1 };
 
 /* array kinds (host shapes) */
 enum { CFD_KIND_CELL_GHOSTED = 0, CFD_KIND_CELL = 1, CFD_KIND_FACE_I = 2, CFD_KIND_FACE_J = 3 };
@@ -225,8 +231,25 @@ int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, dou
  * start-of-step snapshot.                                                */
 int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, double relax_v,
                   double relax_p, double res[3]);
-/* solver.update_turbulence, k-omega (solver.py:1090-1153)                                */
+/* solver.update_turbulence (solver.py:1090-1153): Wilcox k-omega, or Menter SST after
+ * cfd_set_turbulence_model(ctx, CFD_TURB_SST)                                            */
 int cfd_turbulence_step(cfd_ctx *ctx, double dt);
+/* Turbulence closure: CFD_TURB_KOMEGA (default; turbulence.py:19-34, 388-394, 427-444) or CFD_TURB_SST
+ * (Menter SST, turbulence.py:41-208, 343-386, 447-566).  SST allocates its eleven extra planes (six
+ * caches, cell centres, the omega transport operator) once, outside the caller's workspace; single-rank
+ * contexts only.  It needs cfd_upload_cell_centers and cfd_set_wall_faces before the first step.      */
+int cfd_set_turbulence_model(cfd_ctx *ctx, int model);
+/* mesh["cell_center"] (Ni, Nj, 2) (mesh.py:375-394): read by the SST wall distance and the
+ * finite-difference gradients of k and omega (turbulence.py:96-136, 179-208)                          */
+int cfd_upload_cell_centers(cfd_ctx *ctx, const double *cell_center);
+/* Face centres (n, 2) of every boundary face of type "wall", all segments concatenated
+ * (turbulence._wall_face_centers, turbulence.py:69-93); n = 0: no wall (distance 1.0)                 */
+int cfd_set_wall_faces(cfd_ctx *ctx, int n, const double *xy);
+/* Whether the SST caches exist: the reference creates them in the first update_turbulence call and
+ * uses a1 k / omega without limiter until then (turbulence.py:376-386).  set: a restart uploaded the
+ * CFD_F_SST_* planes of a saved state and marks them valid                                            */
+int cfd_sst_get_cached(cfd_ctx *ctx, int *cached);
+int cfd_sst_set_cached(cfd_ctx *ctx, int cached);
 int cfd_get_stats(cfd_ctx *ctx, cfd_solve_stats *out);
 /* volume-weighted mean of u or v over the interior (post_processing.py:602-610)          */
 int cfd_bulk_velocity(cfd_ctx *ctx, int field_id, double *out);

@@ -185,7 +185,7 @@ def test_device_metrics_from_nodes(tag):
 def _run_hip(name, freeze, tmp_path):
     from cfd_amd import mesh as hip_mesh
     from cfd_amd import solver as hip_solver
-    builder, fixup = cases.ALL_END_TO_END[name]
+    builder, fixup = {**cases.ALL_END_TO_END, **cases.SST_END_TO_END}[name]
     cfg, mp, kind = builder()
     gen = hip_mesh.generate_rect_mesh if kind == "rect" else hip_mesh.generate_annulus_mesh
     cfg["mesh"] = {"generator": gen, "params": mp, "path": tmp_path / "mesh" / "mesh.npz"}
@@ -204,6 +204,7 @@ def _run_hip(name, freeze, tmp_path):
 E2E = [(n, "fresh") for n in ("lam_channel", "inlet_outlet_channel", "couette_piso", "half_cylinder",
                               "channel_forced_24")]
 E2E += [(n, "frozen") for n in cases.ALL_END_TO_END]
+E2E += [(n, "frozen") for n in cases.SST_END_TO_END]     # Menter SST: fields include _S, _F1, _F2, _D_k, _D_omega, _d_wall
 
 
 @pytest.mark.parametrize("name,mode", E2E)
@@ -491,3 +492,35 @@ def test_marching_flux_kernels_match_tile_kernels(name, tmp_path):
             assert np.array_equal(mask_corners(fields[key]), mask_corners(ref_fields[key])), (mode, key)
         assert np.array_equal(log[:, 2], ref_log[:, 2])
         assert np.allclose(log[:, 3], ref_log[:, 3], rtol=1e-5, atol=0.0)     # printed with 7 digits
+
+
+def test_committed_reference_sst_run(tmp_path):
+    """Tier A for the SST closure: the reference's own committed 5x20 SST run (real pyamg, rtol 1e-8):
+    first logged steps of the residual / friction logs and states/sst/fields_000000.npz with its caches."""
+    from conftest import GOLDEN
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    cfg, mp, _ = cases.channel_komega_5x20(steps=21, tol=1e-8, model="sst")
+    cfg["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp, "path": tmp_path / "mesh" / "Coarse_mesh.npz"}
+    cfg["paths"] = {"case_dir": tmp_path, "mesh_dir": tmp_path / "mesh", "states_dir": tmp_path / "states",
+                    "post_dir": tmp_path / "postproc"}
+    mesh = hip_mesh.make_mesh(cfg["mesh"])
+    cases.ramp_initial_u(cfg, mesh)
+    cfg["post"]["save_interval"] = 300
+    hip_solver.run_case(cfg)
+    res = np.loadtxt(tmp_path / "postproc" / "channel_sst_residual_log.txt", skiprows=1)
+    fric = np.loadtxt(tmp_path / "postproc" / "channel_sst_friction_log.txt", skiprows=1)
+    rres = np.loadtxt(GOLDEN / "ref_runs" / "channel_sst_residual_log.txt", skiprows=1)[:3]
+    rfric = np.loadtxt(GOLDEN / "ref_runs" / "channel_sst_friction_log.txt", skiprows=1)[:3]
+    assert np.array_equal(res[:, 0], rres[:, 0]) and np.array_equal(res[:, 2], rres[:, 2])
+    assert np.all(np.abs(res[:, 1] - rres[:, 1]) <= 2e-6 * np.maximum(rres[:, 1], 1e-30))
+    assert np.all(np.abs(res[:, 3] - rres[:, 3]) <= 2e-6 * rres[:, 3])
+    for col in (2, 3, 4, 5, 6):
+        assert np.all(np.abs(fric[:, col] - rfric[:, col]) <= 2e-6 * np.abs(rfric[:, col])), col
+    st = load_golden("ref_runs/sst_fields_000000.npz")
+    mine = load_golden(str(tmp_path / "states" / "fields_000000.npz"))
+    assert set(st.keys()) == set(mine.keys())
+    for k in ("u", "k", "omega", "nu_t", "_S", "_F1", "_F2", "_D_k", "_D_omega", "_d_wall"):
+        assert rel_l2(mask_corners(mine[k]), mask_corners(st[k])) < 1e-7, k
+    for k in ("v", "p"):
+        assert np.max(np.abs(mask_corners(mine[k]) - mask_corners(st[k]))) < 1e-9, k
