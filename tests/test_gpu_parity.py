@@ -524,3 +524,49 @@ def test_committed_reference_sst_run(tmp_path):
         assert rel_l2(mask_corners(mine[k]), mask_corners(st[k])) < 1e-7, k
     for k in ("v", "p"):
         assert np.max(np.abs(mask_corners(mine[k]) - mask_corners(st[k]))) < 1e-9, k
+
+
+@pytest.mark.parametrize("name", ["channel_forced_24", "channel_forced_komega_24", "channel_forced_sst_24"])
+def test_restart_continues_the_run(name, tmp_path):
+    """State / restart IO (solver.py:1296-1364, 401-419): 2 steps + save_fields + restart for 2 more steps
+    reproduce the 4-step run (fresh pressure operator each solve, since a restart re-freezes it):
+    the saved state carries everything the step depends on (lagged nu_t, SST caches), the residual log is
+    truncated and continued."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    builder, fixup = {**cases.ALL_END_TO_END, **cases.SST_END_TO_END}[name]
+
+    def make(d, steps):
+        cfg, mp, kind = builder()
+        cfg["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp, "path": d / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": d, "mesh_dir": d / "mesh", "states_dir": d / "states", "post_dir": d / "postproc"}
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        fixup(cfg, mesh)
+        cfg["time"]["max_steps"] = steps
+        cfg["solver"]["pressure"]["freeze_operator"] = False
+        cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+        return cfg, mesh
+
+    cfg, mesh = make(tmp_path / "whole", 4)
+    ref, step, time = hip_solver.run_case(cfg)
+    assert step == 4
+    ref_log = np.loadtxt(tmp_path / "whole" / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+
+    cfg, mesh = make(tmp_path / "split", 2)
+    f1, s1, t1 = hip_solver.run_case(cfg)
+    state = hip_solver.save_fields(mesh, f1, tmp_path / "split" / "states", s1, t1)
+    cfg, mesh = make(tmp_path / "split", 2)
+    cfg["restart"] = {"enabled": True, "path": state}
+    got, step2, time2 = hip_solver.run_case(cfg)
+    assert step2 == 4 and abs(time2 - time) <= 1e-12 * time
+    assert set(got) == set(ref)
+    unorm = np.linalg.norm(ref["u"].ravel())
+    for key in ref:
+        if key == "p_corr":
+            continue
+        err = np.linalg.norm((mask_corners(got[key]) - mask_corners(ref[key])).ravel())
+        den = np.linalg.norm(mask_corners(ref[key]).ravel())
+        assert err <= 1e-9 * den + 1e-12 * unorm, (key, err, den)
+    log = np.loadtxt(tmp_path / "split" / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+    assert np.array_equal(log[:, 0], ref_log[:, 0])
+    assert np.allclose(log[:, 3], ref_log[:, 3], rtol=2e-6, atol=0.0)
