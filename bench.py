@@ -230,7 +230,7 @@ def main():
             "data": "synthetic" if not args.shared_gpu else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
             "config": {"workload": f"synthetic {n}x{n} periodic channel with pressure-gradient forcing "
                                    f"({'k-omega' if args.turbulent else 'laminar'}), SIMPLE max_iter={args.max_iter}, "
-                                   f"continuity_tol=0, cfl=cfl_diff=0.5, dt_max=1e-3, rtol={args.tol:g}",
+                                   f"continuity_tol=0, cfl=cfl_diff=0.5, dt_max={cfg['time']['dt_max']:.3g}, rtol={args.tol:g}",
                        "cells_per_gpu": n * n,
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel (height {world}), halo exchange + "

@@ -182,10 +182,12 @@ struct cfd_ctx {
     if (hipSetDevice(c->device) != hipSuccess) { cfd::set_error("hipSetDevice failed"); return CFD_E_HIP; }
 
 // every entry point that may change fields, operators, parameters or the b_u / b_v planes drops the
-// momentum right-hand sides that the previous inner iteration computed ahead of time
-#define CTX_MUT(ctx) \
-    CTX(ctx)         \
-    c->rhs_ahead = false;
+// momentum right-hand sides that the previous inner iteration computed ahead of time and the cached
+// a_P / a_i / a_j planes
+#define CTX_MUT(ctx)       \
+    CTX(ctx)               \
+    c->rhs_ahead = false;  \
+    c->ap_cached = false;
 
 #define NEED_MESH()                                                           \
     if (!c->mesh_set) { cfd::set_error("mesh not uploaded"); return CFD_E_STATE; }
@@ -484,7 +486,7 @@ int cfd_upload_field(cfd_ctx *ctx, int field_id, const double *host, int kind) {
     double *pl = field_plane(c, field_id);
     if (!pl || !host || kind < 0 || kind > 3) { set_error("cfd_upload_field: bad arguments"); return CFD_E_ARG; }
     CFD_TRY(to_device(c, host, pl, kind));
-    if (field_id == CFD_F_NUT || field_id == CFD_F_AP || field_id == CFD_F_AI || field_id == CFD_F_AJ) c->ap_cached = false;
+    if (field_id != CFD_F_U && field_id != CFD_F_V && field_id != CFD_F_P && field_id != CFD_F_PCORR) c->ap_cached = false;
     if (field_id == CFD_F_SST_DWALL) c->sst_dw_set = true;
     // u, v, p exist twice (ping-pong): keep never-written ghosts (corners) identical in both
     if (field_id == CFD_F_U) CFD_TRY(launch_copy_plane(c, pl, c->U1()));
@@ -704,14 +706,16 @@ static int flow_bc(Ctx *c, double *u, double *v, double *p) {
 static int do_predictor(Ctx *c, double dt, double res[3]) {
     {
         Phase ph(c, PH_ADV);
-        // laminar runs: nu_t = 0 for good, so a_P / a_i / a_j depend on dt only and are rebuilt only when
-        // dt changes (the reference rebuilds the same numbers every inner iteration, solver.py:868-876)
-        if (c->turbulent || !c->ap_cached || c->dt_ap != dt) {
+        // a_P / a_i / a_j depend on nu_t and dt only: nu_t = 0 for good in laminar runs, and k, omega change
+        // only in the turbulence step (which drops the cache, like every upload of k, omega, nu_t), so they
+        // are rebuilt when dt changes or after a turbulence update -- the reference rebuilds the same
+        // numbers every inner iteration (solver.py:1600-1601, 868-876)
+        if (!c->ap_cached || c->dt_ap != dt) {
             CFD_TRY(launch_eddy_viscosity(c));
             CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
             CFD_TRY(halo_exchange(c, c->g, 1, c->ap));     // Rhie-Chow and d_f read a_P across the cut
             c->dt_ap = dt;
-            c->ap_cached = !c->turbulent;
+            c->ap_cached = true;
             c->rho_cached = -1.0;
         }
         // b_u, b_v may already be there: the fused continuity pass of the previous inner iteration
