@@ -157,6 +157,7 @@ struct Ctx {
     int l_agg = 0;               // j-slab runs: first replicated level (levels below it are slabs); 0 = single rank
     Comm comm;
     bool p_built = false;
+    int p_iters_hint = 0;         // PCG iterations of the previous solve with the current operator (0: unknown)
     bool p_symmetric = true;
     DiagFix p_diag;
     int recompute_diag = 1;
@@ -297,7 +298,7 @@ int read_scalars(Ctx *c, int off, int n, double *host);
 int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2], int nb,
                         double tol, int maxiter, int *iters, double relres[2], double rms[2]);
 int build_pressure_hierarchy(Ctx *c);
-int pressure_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres);
+int pressure_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres);   // b is a work plane: PCG turns it into the residual in place
 int vcycle(Ctx *c, const double *r, double *z);
 int launch_spmv(Ctx *c, const OpDev &op, const double *x, double *y);
 int time_kernel(Ctx *c, int kernel, int reps, double *avg_us);

@@ -1510,6 +1510,7 @@ __global__ void k_seam_asym(Geo g, const double *ci, const double *cj, int per_i
 }
 
 int build_pressure_hierarchy(Ctx *c) {
+    c->p_iters_hint = 0;
     Level &L0 = c->levels[0];
     CFD_TRY(launch_pressure_coeffs(c, L0));
     hipStream_t st = c->stream;
@@ -1760,8 +1761,8 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 // 72 B/cell (z, p, x, D, c_i, c_j read; p', q, x written) instead of 24 + 40 for k_cg_p + k_cg_q and
 // 16 of the 48 of k_cg_xr, whose remainder is k_cg_r below.  p' goes to a second plane: neighbouring
 // strips recompute p' on their halo from the old p.
-__global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen, int first, const double *z,
-                                               const double *pold, double *pnew, double *q, double *x, double *partials) {
+__global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen, int first, int xzero,
+                                               const double *z, const double *pold, double *pnew, double *q, double *x, double *partials) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
@@ -1793,7 +1794,7 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df
             R.cell = cc;
             R.po = first ? 0.0 : pold[cc];
             R.z = z[cc];
-            R.xv = first ? 0.0 : x[cc];
+            R.xv = (first || xzero) ? 0.0 : x[cc];      // xzero: x = 0 was never stored (second iteration)
             R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
             // rows j0-1 .. j1 only: the outermost halo row is never touched here
@@ -1844,11 +1845,11 @@ __global__ void k_cg_r(Geo g, Tiling T, const CgScal *s, int gen, const double *
     block_sums<1>(acc, partials);
 }
 // x += alpha p  (the update the fused direction step still owes after the last iteration)
-__global__ void k_cg_xlast(Geo g, Tiling T, const CgScal *s, int gen, const double *p, double *x) {
+__global__ void k_cg_xlast(Geo g, Tiling T, const CgScal *s, int gen, int xzero, const double *p, double *x) {
     const double alpha = safe_div(s->rz[gen], s->pq);
     TILE_LOOP(g, T) {
         const size_t c = g.cell(i, j);
-        x[c] = x[c] + alpha * p[c];
+        x[c] = (xzero ? 0.0 : x[c]) + alpha * p[c];
     }
 }
 
@@ -1868,7 +1869,15 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     mgeo.nstrips = (g.ni + 61) / 62;
     const dim3 mgrid(march_blocks(mgeo));
     CFD_HIP(hipMemsetAsync(S, 0, sizeof(CgScal), st));
-    hipLaunchKernelGGL(k_cg_init, grid, blk, 0, st, g, T, b, r, x, c->partials);
+    if (fused) {
+        // the right-hand side plane is a work plane of the caller: it becomes the residual in place, and
+        // x = 0 is never stored (the first two direction steps and k_cg_xlast know it)
+        r = const_cast<double *>(b);
+        CVecs<1> a1{{b}};
+        hipLaunchKernelGGL((k_dot<1>), grid, blk, 0, st, g, T, a1, a1, c->partials);
+    } else {
+        hipLaunchKernelGGL(k_cg_init, grid, blk, 0, st, g, T, b, r, x, c->partials);
+    }
     CFD_HIP(hipGetLastError());
     CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(bb)));
     double bb, rr;
@@ -1876,7 +1885,10 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     if (!(bb == bb)) { set_error("pressure solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
     *iters = 0;
     *relres = 0.0;
-    if (bb == 0.0) return CFD_OK;
+    if (bb == 0.0) {
+        if (fused) CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
+        return CFD_OK;
+    }
     rr = bb;
     int it = 0;
     while (it < maxiter) {
@@ -1897,7 +1909,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             p = pbuf[gen];
             CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
             c->probe_begin(0);
-            hipLaunchKernelGGL(k_cg_pq, mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, z, pold, p, q, x, c->partials);
+            hipLaunchKernelGGL(k_cg_pq, mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, it == 1, z, pold, p, q, x, c->partials);
             c->probe_end(0);
             CFD_HIP(hipGetLastError());
             CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));
@@ -1915,13 +1927,20 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         CFD_HIP(hipGetLastError());
         CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rr)));
         ++it;
+        // The host looks at |r| (one stream synchronisation, during which the GPU idles) only from two
+        // iterations before the count the previous solve with this frozen operator needed; the stopping
+        // test itself is unchanged.
+        if (it + 2 < c->p_iters_hint && it < maxiter) continue;
         CFD_TRY(read_scalars(c, CG_OFF_OF(rr), 1, &rr));
         if (!(rr == rr)) { set_error("PCG: non-finite residual at iteration %d", it); return CFD_E_NUMERIC; }
         if (sqrt(rr) <= tol * sqrt(bb)) break;
     }
+    c->p_iters_hint = it;
     if (fused && it > 0) {
-        hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, p, x);
+        hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, it == 1, p, x);
         CFD_HIP(hipGetLastError());
+    } else if (fused) {
+        CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
     }
     *iters = it;
     *relres = sqrt(rr / bb);
