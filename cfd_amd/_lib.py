@@ -70,6 +70,7 @@ SIGNATURES = {
     "cfd_set_transport_solver": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int]),
     "cfd_set_smoother_omega2": (C.c_int, [_vp, C.c_double]),
     "cfd_set_flux_kernels": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "cfd_set_pressure_nullspace": (C.c_int, [_vp, C.c_int]),
     "cfd_set_turbulence_model": (C.c_int, [_vp, C.c_int]),
     "cfd_upload_cell_centers": (C.c_int, [_vp, _dp]),
     "cfd_set_wall_faces": (C.c_int, [_vp, C.c_int, _dp]),

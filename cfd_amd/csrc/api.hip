@@ -562,6 +562,13 @@ int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2) {
     return CFD_OK;
 }
 
+int cfd_set_pressure_nullspace(cfd_ctx *ctx, int on) {
+    CTX_MUT(ctx);
+    c->p_nullspace = on ? 1 : 0;
+    c->p_built = false;
+    return CFD_OK;
+}
+
 int cfd_set_flux_kernels(cfd_ctx *ctx, int marching, int lookahead) {
     CTX_MUT(ctx);
     c->march_flux = marching ? 1 : 0;

@@ -159,6 +159,14 @@ struct Ctx {
     bool p_built = false;
     int p_iters_hint = 0;         // PCG iterations of the previous solve with the current operator (0: unknown)
     bool p_symmetric = true;
+    // Pure-Neumann / periodic pressure systems (no Dirichlet p anywhere): the reference pins one cell
+    // (solver.py:1033-1044).  The detached cell costs the V-cycle-preconditioned CG two of its ten iterations
+    // at 8192^2, so the symmetric case solves the singular system instead (all rows kept, right-hand side
+    // made compatible at the reference cell's own row, which is the row the reference drops) and shifts
+    // the solution to the pinned value afterwards: the same p' up to rounding.  p_ns_active is decided when
+    // the operator is built; non-symmetric operators (BiCGStab) keep the eliminated cell.
+    int p_nullspace = 1;
+    bool p_ns_active = false;
     DiagFix p_diag;
     int recompute_diag = 1;
     int pin_i_any = -1, pin_j_rel = -1;   // reference cell as given (slab runs: row relative to this slab)
@@ -267,7 +275,8 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
 int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, const double *p, double *cont = nullptr);
 int launch_turb_rhs(Ctx *c, double dt);
 int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b);
-int launch_pressure_coeffs(Ctx *c, Level &L);
+int launch_pressure_coeffs(Ctx *c, Level &L);     // unpinned face planes and diagonal
+int launch_pin_operator(Ctx *c, Level &L);         // detach the reference cell (solver.py:1033-1044)
 int launch_pcorr_bc(Ctx *c);
 int launch_correct(Ctx *c, const double *us, const double *vs, const double *u0, const double *v0,
                    const double *p0, double *uo, double *vo, double *po, double ru, double rv, double rp);

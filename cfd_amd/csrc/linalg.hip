@@ -1514,13 +1514,26 @@ int build_pressure_hierarchy(Ctx *c) {
     Level &L0 = c->levels[0];
     CFD_TRY(launch_pressure_coeffs(c, L0));
     hipStream_t st = c->stream;
+    // symmetric unless a periodic seam carries different coefficients on its two copies
+    c->p_symmetric = true;
+    if (c->pp_per_i || c->pp_per_j) {
+        hipLaunchKernelGGL(k_seam_asym, dim3(1), dim3(256), 0, st, c->g, L0.ci, L0.cj, c->pp_per_i, c->pp_per_j,
+                           c->scal + 8);
+        CFD_HIP(hipGetLastError());
+        double a[2];
+        CFD_TRY(all_reduce(c, c->scal + 8, 2, 0));
+        CFD_TRY(read_scalars(c, 8, 2, a));
+        c->p_symmetric = !(a[0] > 1.0e-13 * a[1]);
+    }
+    c->p_ns_active = !c->has_dirichlet && c->p_symmetric && c->p_nullspace;
+    if (!c->p_ns_active) CFD_TRY(launch_pin_operator(c, L0));
     // finest-level diagonal from the face planes (see diag_from_faces): every rank needs the four
     // couplings of the detached reference cell, which only its owner knows
     c->p_diag = DiagFix{};
     if (c->recompute_diag) {
         DiagFix f{};
         f.on = 1; f.pi = -1; f.pj = -1;
-        if (!c->has_dirichlet) {
+        if (!c->has_dirichlet && !c->p_ns_active) {
             if (c->pin_i < 0) CFD_HIP(hipMemsetAsync(c->scal + 64, 0, 8 * sizeof(double), st));
             CFD_TRY(all_reduce(c, c->scal + 64, 8, 0));
             double pc[8];
@@ -1559,16 +1572,6 @@ int build_pressure_hierarchy(Ctx *c) {
         } else if (l + 1 < la) {
             CFD_TRY(halo_exchange(c, C.g, 2, C.ci, C.cj, C.D));
         }
-    }
-    c->p_symmetric = true;
-    if (c->pp_per_i || c->pp_per_j) {
-        hipLaunchKernelGGL(k_seam_asym, dim3(1), dim3(256), 0, st, c->g, L0.ci, L0.cj, c->pp_per_i, c->pp_per_j,
-                           c->scal + 8);
-        CFD_HIP(hipGetLastError());
-        double a[2];
-        CFD_TRY(all_reduce(c, c->scal + 8, 2, 0));
-        CFD_TRY(read_scalars(c, 8, 2, a));
-        c->p_symmetric = !(a[0] > 1.0e-13 * a[1]);
     }
     c->p_built = true;
     return CFD_OK;
@@ -1845,12 +1848,40 @@ __global__ void k_cg_r(Geo g, Tiling T, const CgScal *s, int gen, const double *
     block_sums<1>(acc, partials);
 }
 // x += alpha p  (the update the fused direction step still owes after the last iteration)
-__global__ void k_cg_xlast(Geo g, Tiling T, const CgScal *s, int gen, int xzero, const double *p, double *x) {
+__global__ void k_cg_xlast(Geo g, Tiling T, const CgScal *s, int gen, int xzero, const double *p, const double *shift, double *x) {
     const double alpha = safe_div(s->rz[gen], s->pq);
+    const double sh = shift ? shift[0] : 0.0;
     TILE_LOOP(g, T) {
         const size_t c = g.cell(i, j);
-        x[c] = (xzero ? 0.0 : x[c]) + alpha * p[c];
+        x[c] = ((xzero ? 0.0 : x[c]) + alpha * p[c]) + sh;
     }
+}
+// nullspace form: the constant that moves the solution to the reference value at the reference cell;
+// with_p: the last x += alpha p is still owed (fused path)
+__global__ void k_ns_shift(Geo g, int pi, int pj, double value, const CgScal *s, int gen, int with_p, int xzero, const double *p,
+                           const double *x, double *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const size_t c = g.cell(pi, pj);
+    double xr = xzero ? 0.0 : x[c];
+    if (with_p) xr = xr + safe_div(s->rz[gen], s->pq) * p[c];
+    out[0] = value - xr;
+}
+__global__ void k_add_scalar(Geo g, Tiling T, const double *sh, double *x) {
+    const double v = sh[0];
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+        x[c] = x[c] + v;
+    }
+}
+// scal[81] = shift (owner rank computes it, the other slabs contribute zero to the sum)
+static int ns_shift_scalar(Ctx *c, const CgScal *S, int gen, int with_p, int xzero, const double *p, const double *x) {
+    if (c->pin_i >= 0)
+        hipLaunchKernelGGL(k_ns_shift, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->pin_value, S, gen, with_p, xzero,
+                           p, x, c->scal + 81);
+    else
+        CFD_HIP(hipMemsetAsync(c->scal + 81, 0, sizeof(double), c->stream));
+    CFD_HIP(hipGetLastError());
+    return all_reduce(c, c->scal + 81, 1, 0);
 }
 
 static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres) {
@@ -1887,6 +1918,11 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     *relres = 0.0;
     if (bb == 0.0) {
         if (fused) CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
+        if (c->p_ns_active && c->pin_value != 0.0) {
+            CFD_TRY(ns_shift_scalar(c, S, 0, 0, 1, x, x));
+            hipLaunchKernelGGL(k_add_scalar, grid, blk, 0, st, g, T, c->scal + 81, x);
+            CFD_HIP(hipGetLastError());
+        }
         return CFD_OK;
     }
     rr = bb;
@@ -1937,10 +1973,17 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     }
     c->p_iters_hint = it;
     if (fused && it > 0) {
-        hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, it == 1, p, x);
+        if (c->p_ns_active) CFD_TRY(ns_shift_scalar(c, S, (it - 1) & 1, 1, it == 1, p, x));
+        hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, it == 1, p,
+                           c->p_ns_active ? c->scal + 81 : (const double *)nullptr, x);
         CFD_HIP(hipGetLastError());
-    } else if (fused) {
-        CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
+    } else {
+        if (fused) CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
+        if (c->p_ns_active) {
+            CFD_TRY(ns_shift_scalar(c, S, 0, 0, 0, x, x));
+            hipLaunchKernelGGL(k_add_scalar, grid, blk, 0, st, g, T, c->scal + 81, x);
+            CFD_HIP(hipGetLastError());
+        }
     }
     *iters = it;
     *relres = sqrt(rr / bb);

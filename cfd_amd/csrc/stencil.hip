@@ -573,13 +573,13 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 const double vol = prv.vol;
                 const double div = (fe_p - fw_p + fs_c - fs_p) / vol;
                 if (MODE == 0) acc += div * div;
-                else bout[(size_t)(jo + 2) * P + colo] = vol * (-div);
+                else { const double bv = vol * (-div); bout[(size_t)(jo + 2) * P + colo] = bv; acc += bv; }   // sum b (nullspace form)
             }
             fw_p = fw_c; fs_p = fs_c;
             prv = cur;
         }
     }
-    if (MODE != 1) {
+    {
         __shared__ double sm[4];
         const double w = wave_sum(acc);
         if (lane == 0) sm[wave] = w;
@@ -744,6 +744,20 @@ __global__ void k_pin_rhs(Geo g, int pi, int pj, double value, const double *pin
     else if (per_j && g.nj > 1) b[c - (size_t)(g.nj - 1) * P] += pin_coef[3] * value;
 }
 
+__global__ void k_plane_sum(Geo g, const double *f, double *partials, int tiles_x, int tiles) {
+    double a = 0.0;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int i = (tile % tiles_x) * 64 + threadIdx.x, j = (tile / tiles_x) * 4 + threadIdx.y;
+        if (i >= g.ni || j >= g.nj) continue;
+        a += f[g.cell(i, j)];
+    }
+    a = block_sum_256(a);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = a;
+}
+__global__ void k_ns_rhs(Geo g, int pi, int pj, const double *total, double *b) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) b[g.cell(pi, pj)] -= total[0];
+}
+
 int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b) {
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
     if (c->march_flux) {
@@ -754,6 +768,24 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
         hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
     }
     CFD_HIP(hipGetLastError());
+    if (!c->has_dirichlet && c->p_ns_active) {
+        // singular (nullspace) form: every row is kept; the reference cell's row -- the one the reference
+        // replaces -- absorbs the global imbalance, b_ref -= sum(b), so that the system is compatible
+        if (c->march_flux) {
+            c->n_red_blocks = flux_march_geo(c->g).blocks;
+        } else {
+            int tx;
+            const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
+            hipLaunchKernelGGL(k_plane_sum, dim3(nb), block2d(), 0, c->stream, c->g, b, c->partials, tx, tiles);
+            c->n_red_blocks = nb;
+        }
+        CFD_TRY(reduce_finish(c, 1, 80));               // scal[80] = sum over all slabs
+        if (c->pin_i >= 0) {
+            hipLaunchKernelGGL(k_ns_rhs, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->scal + 80, b);
+            CFD_HIP(hipGetLastError());
+        }
+        return CFD_OK;
+    }
     if (!c->has_dirichlet && c->pin_i >= 0) {      // pin_i < 0: the reference cell lives on another slab
         const Level &L = c->levels[0];
         hipLaunchKernelGGL(k_pin_rhs, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->pin_value,
@@ -838,6 +870,10 @@ int launch_pressure_coeffs(Ctx *c, Level &L) {
     hipLaunchKernelGGL(k_pressure_coeffs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->ap, pm,
                        c->pp_per_i, c->pp_per_j, L.ci, L.cj, L.D);
     CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+int launch_pin_operator(Ctx *c, Level &L) {
     if (!c->has_dirichlet && c->pin_i >= 0) {
         hipLaunchKernelGGL(k_pin_operator, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->pp_per_i,
                            c->pp_per_j, L.ci, L.cj, c->scal + 64);

@@ -194,6 +194,9 @@ class Device:
         check(self.lib.cfd_set_transport_solver(self._h, int(bool(warm_start)), int(bool(chebyshev)), float(rho_max),
                                                 int(max_iters)))
 
+    def set_pressure_nullspace(self, on=True):
+        check(self.lib.cfd_set_pressure_nullspace(self._h, int(bool(on))))
+
     def set_flux_kernels(self, marching=True, lookahead=True):
         check(self.lib.cfd_set_flux_kernels(self._h, int(bool(marching)), int(bool(lookahead))))
 

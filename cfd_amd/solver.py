@@ -270,6 +270,7 @@ def configure_device(dev, config, geometry, nu, turb_on):
     tr = solver_cfg.get("transport", {})
     dev.set_transport_solver(tr.get("warm_start", True), tr.get("chebyshev", True), tr.get("rho_max", 0.95),
                              tr.get("max_iters", 80))
+    dev.set_pressure_nullspace(pressure_cfg.get("nullspace", True))
     fk = solver_cfg.get("flux_kernels", {})
     dev.set_flux_kernels(fk.get("marching", True), fk.get("lookahead", True))
     params = config.get("turbulence", {}).get("params", {})

@@ -176,6 +176,13 @@ int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int c
  * spectrum; omega2 <= 0 (default): plain damped Jacobi.  The single-block coarsest solve always uses
  * `omega`.  (Replaces pyamg's smoother choice, solver.py:821-833.)                                  */
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
+/* Systems without any Dirichlet pressure (the reference pins one cell, solver.py:1033-1044):
+ *   on = 1 (default): when the operator is symmetric the singular system is solved with every row kept
+ *   (right-hand side made compatible at the reference cell's row, the row the reference drops) and the
+ *   solution is shifted to the reference value: the same p' up to rounding, two V-cycle-PCG iterations
+ *   fewer at 8192^2;  on = 0: the reference cell is eliminated symmetrically.  Non-symmetric operators
+ *   (periodic seam with varying coefficients, MG-BiCGStab) always eliminate the cell.                 */
+int cfd_set_pressure_nullspace(cfd_ctx *ctx, int on);
 /* Form of the Rhie-Chow flux kernels (solver.py:455-513, 672-691, 926-933, 1205-1215).
  *   marching  : 1 (default) = one wavefront per 62-column strip walking down the rows, every face flux
  *               evaluated once; 0 = the 64x4-tile kernels (same bits, 1.5-1.9x the HBM traffic);

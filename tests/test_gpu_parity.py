@@ -300,9 +300,20 @@ def test_linear_algebra_against_scipy():
     z = dev.vcycle(b)
     r1 = np.linalg.norm(b.ravel() - a_p.dot(z.ravel())) / np.linalg.norm(b.ravel())
     assert r1 < 0.6, f"one V-cycle must contract the residual, got {r1}"
+    # no Dirichlet p: the symmetric operator is solved in its singular (nullspace) form and shifted to the
+    # reference value at the reference cell; with the cell eliminated instead the system is regular
+    ref_cell = tuple(bc_cfg["pressure_reference"]["cell"])
     sol, iters, relres = dev.pressure_krylov(b, tol=1e-12, maxiter=200)
     assert relres <= 1e-12 and iters < 60
-    assert rel_l2(sol, x) < 1e-9
+    assert abs(sol[ref_cell] - bc_cfg["pressure_reference"]["value"]) < 1e-12
+    assert rel_l2(sol - sol[ref_cell], x - x[ref_cell]) < 1e-9
+    dev.set_pressure_nullspace(False)
+    ci, cj, diag, _ = dev.pressure_system()
+    a_pin = orc.five_point_matrix(diag, ci[:-1], ci[1:], cj[:, :-1], cj[:, 1:], True, False)
+    b_pin = a_pin.dot(x.ravel()).reshape(ni, nj)
+    sol2, iters2, relres2 = dev.pressure_krylov(b_pin, tol=1e-12, maxiter=200)
+    assert relres2 <= 1e-12 and iters2 < 60 and iters <= iters2
+    assert rel_l2(sol2, x) < 1e-9
     dev.close()
 
 
@@ -480,6 +491,9 @@ def test_marching_flux_kernels_match_tile_kernels(name, tmp_path):
             fixup(cfg, mesh)
         cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
         cfg["solver"]["flux_kernels"] = {"marching": marching, "lookahead": lookahead}
+        # the nullspace form of the pressure system adds sum(b), whose summation order differs between the two
+        # kernel forms (last-bit differences in p'); with the reference cell eliminated everything is bit-identical
+        cfg["solver"]["pressure"]["nullspace"] = False
         fields, step, time = hip_solver.run_case(cfg)
         log = np.loadtxt(d / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
         out[mode] = (fields, log)
@@ -570,3 +584,30 @@ def test_restart_continues_the_run(name, tmp_path):
     log = np.loadtxt(tmp_path / "split" / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
     assert np.array_equal(log[:, 0], ref_log[:, 0])
     assert np.allclose(log[:, 3], ref_log[:, 3], rtol=2e-6, atol=0.0)
+
+
+@pytest.mark.parametrize("name", ["lam_channel", "couette_piso", "channel_komega_5x20"])
+def test_pressure_nullspace_form_matches_pinned_cell(name, tmp_path):
+    """Cases without Dirichlet pressure: solving the singular system and shifting to the reference value
+    gives the fields of the eliminated-reference-cell form (the reference's, solver.py:1033-1044)."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    out = {}
+    for mode in (True, False):
+        d = tmp_path / str(mode)
+        builder, fixup = cases.ALL_END_TO_END[name]
+        cfg, mp, kind = builder()
+        cfg["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp, "path": d / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": d, "mesh_dir": d / "mesh", "states_dir": d / "states", "post_dir": d / "postproc"}
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        if fixup is not None:
+            fixup(cfg, mesh)
+        cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+        cfg["solver"]["pressure"]["nullspace"] = mode
+        out[mode], _, _ = hip_solver.run_case(cfg)
+    unorm = np.linalg.norm(out[False]["u"].ravel())
+    for key in out[False]:
+        if key == "p_corr":
+            continue
+        a, b = mask_corners(out[True][key]), mask_corners(out[False][key])
+        assert np.linalg.norm((a - b).ravel()) <= 1e-9 * np.linalg.norm(b.ravel()) + 1e-12 * unorm, key
