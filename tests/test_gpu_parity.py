@@ -465,8 +465,10 @@ def test_chebyshev_transport_matches_bicgstab(turbulent, tmp_path):
                 continue
             den = max(np.linalg.norm(mask_corners(ref[key]).ravel()), 1e-300)
             err = np.linalg.norm((mask_corners(a) - mask_corners(ref[key])).ravel())
-            # p integrates the O(tol) velocity differences with a 1/dt weight
-            assert err <= (1e-6 if key == "p" else 1e-9) * den + 1e-12, (mode, key, err, den)
+            # p integrates the O(tol) velocity differences with a 1/dt weight; v is tiny against u, and both
+            # solvers stop at tol |b| of their own component, hence the floor in units of |u|
+            unorm = np.linalg.norm(mask_corners(ref["u"]).ravel())
+            assert err <= (1e-6 if key == "p" else 1e-9) * den + 1e-12 * unorm, (mode, key, err, den)
 
 
 @pytest.mark.parametrize("name", ["half_cylinder_komega", "inlet_outlet_channel", "couette_piso", "channel_forced_24"])
