@@ -712,8 +712,8 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, DiagFix 
             R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
             // the outermost halo row of a high slab cut has no north face in memory: its D is read
-            R.d = (FINE && df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
-            if (!(FINE && df.on) || mr == g.nj + 3) R.row = -1000000;
+            R.d = (df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
+            if (!df.on || mr == g.nj + 3) R.row = -1000000;
         };
         auto mk = [&](const Raw &R) -> RowC {
             const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
@@ -807,8 +807,8 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df
             R.e = e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
             R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
-            R.d = (FINE && df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
-            R.row = (!(FINE && df.on) || mr == g.nj + 3) ? -1000000 : js;
+            R.d = (df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
+            R.row = (!df.on || mr == g.nj + 3) ? -1000000 : js;
         };
         auto mk = [&](const Raw &R) -> RowC {
             const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
@@ -1623,6 +1623,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         rhs[l] = (l == 0) ? r : c->levels[l].b;
     }
     const int la = c->l_agg;   // levels [0, la) are j-slabs with halo exchange, the rest is replicated
+    // Without any Dirichlet pressure and in the nullspace form, every level's diagonal is exactly the sum of
+    // its four face planes (the coarsening adds D - sum(faces) = 0), so the coarse levels need not read D either
+    DiagFix coarse_df{};
+    if (c->p_ns_active && c->recompute_diag) { coarse_df.on = 1; coarse_df.pi = -1; coarse_df.pj = -1; }
     for (int l = 0; l < nl - 1; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
@@ -1639,7 +1643,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
                 c->probe_end(1);
             } else {
-                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, DiagFix{}, rhs[l], om, om2, cur[l], cg, cb);
+                hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om, om2, cur[l], cg, cb);
             }
             CFD_HIP(hipGetLastError());
         } else {
@@ -1698,7 +1702,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 c->probe_end(7);
                 *dot_blocks = (int)grid.x;
             } else {
-                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, DiagFix{}, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
+                hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);
             }
             std::swap(cur[l], oth[l]);

@@ -362,7 +362,7 @@ def test_fused_vcycle_matches_unfused(kind, ni, nj):
     dev.close()
 
 
-@pytest.mark.parametrize("n", [512])
+@pytest.mark.parametrize("n", [512, 8192])      # 8192: BASELINE.json's full benchmark size (28 GB workspace)
 def test_properties_at_scale(n):
     """Size-independent checks where the oracle is too slow: (1) the pressure correction makes
     the corrected field discretely divergence-free to solver tolerance with relax = 1 is not
@@ -397,6 +397,11 @@ def test_properties_at_scale(n):
     assert st["p_relres"] <= 1e-10 and max(st["mom_relres"]) <= 1e-10
     u = dev.download(L.F_U)
     assert np.abs(u[1:-1, 1:-1] - u[1:2, 1:-1]).max() <= 1e-9, "i-homogeneous state must stay i-homogeneous"
+    if n > 1024:
+        # the Poiseuille check below takes dt = 1e-3, 270 diffusive time-step limits at 8192^2: a different,
+        # badly conditioned solve that says nothing about the benchmark configuration
+        dev.close()
+        return
     # Poiseuille balance: with u(y) parabolic of amplitude -dpdx H^2/(8 nu) the state is steady
     amp = 0.1 / (8.0 * nu)
     f["u"][1:-1, 1:-1] = (amp * (1.0 - (2.0 * yc - 1.0) ** 2))[None, :]
