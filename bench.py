@@ -15,7 +15,7 @@ The JSON line also carries
                  achieved = 64 B/cell * Ni*Nj / avg duration (z, p, x, c_i, c_j read; p', q, x
                  written).  --probe 8 / 7 / 1 select the momentum Chebyshev kernel / the multigrid up /
                  down kernels instead.  traffic = HBM bytes per launch from the committed PMC passes
-                 of this command (profiles/r1g_pmc8192_bytes_per_cell.csv), quoted only for the
+                 of this command (profiles/r1i_pmc8192_bytes_per_cell.csv), quoted only for the
                  single-GPU default size they were measured on.
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
                  factor-once LU pressure) timed on this host, bounded sample.
@@ -37,8 +37,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
-# 8192^2 (profiles/r1g_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 61.89, 8: 110.41, 7: 45.88, 1: 37.03, 2: 117.62}
+# 8192^2 (profiles/r1i_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 57.64, 8: 108.55, 7: 42.05, 1: 34.32, 2: 117.58}
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1):
@@ -246,8 +246,9 @@ def main():
         }
         # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes of one
         # MG-PCG iteration over all levels: finest level 64 (k_cg_pq) + 24 (k_cg_r) + 34 (k_mg_down)
-        # + 42 (k_mg_up) B/cell (diagonal recomputed from the face planes), coarser levels (42 + 50) / 3 B/cell.
-        pcg_bytes_per_cell_iter = 64 + 24 + 34 + 42 + (42 + 50) / 3.0
+        # + 42 (k_mg_up) B/cell (diagonal recomputed from the face planes on every level of this all-Neumann /
+        # periodic system), coarser levels (34 + 42) / 3 B/cell.
+        pcg_bytes_per_cell_iter = 64 + 24 + 34 + 42 + (34 + 42) / 3.0
         n_solves = extra_steps * args.max_iter
         press_s = phases["press"] / n_solves
         mean_p_it = float(np.mean(p_its))
