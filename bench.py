@@ -152,7 +152,7 @@ def main():
     n = args.size
     dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, world)
     if args.mg_omega is not None or args.mg_omega2 is not None:
-        dev.set_multigrid(omega=args.mg_omega or 0.8, omega2=args.mg_omega2 or 0.0)
+        dev.set_multigrid(omega=args.mg_omega or 1.0, omega2=args.mg_omega2 if args.mg_omega2 is not None else 0.6)
     step = 0
     iters = []
     for _ in range(args.warmup):

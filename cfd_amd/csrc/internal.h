@@ -197,7 +197,10 @@ struct Ctx {
     int mom_maxiter = 200, p_maxiter = 200, turb_maxiter = 200, freeze_pressure = 1;
     int mg_pre = 2, mg_post = 2, mg_coarse_sweeps = 40, mg_min = 4;
     double mg_gamma = 1.0;       // scaling of the prolongated coarse correction
-    double mg_omega = 0.8, mg_omega2 = 0.0;   // omega2 <= 0: same damping on every sweep
+    // Jacobi damping of the even / odd smoothing sweeps (omega2 <= 0: omega on every sweep).  The pair
+    // (1.0, 0.6) has the smoothing factor of (0.8, 0.8) on [0.5, 2] (0.35 vs 0.36) but damps the middle of
+    // the spectrum harder: (1 - x)(1 - 0.6 x); 7.0 instead of 7.2-7.5 PCG iterations at 8192^2.
+    double mg_omega = 1.0, mg_omega2 = 0.6;
     int warm_start = 1;          // Krylov initial guess = previous field (reference: zero)
     int use_chebyshev = 1;       // Chebyshev semi-iteration for time-step dominated transport systems
     double cheb_rho_max = 0.95;  // ... i.e. Jacobi row-sum bound below this

@@ -1669,13 +1669,16 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (nl == 1) {
             // single-level "hierarchy": plain Jacobi sweeps
             const Tiling T = tiling(L.g);
-            hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[0], om, cur[0]);
+            const double omc = 0.5 * (om + om2);
+            hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[0], omc, cur[0]);
             for (int s = 1; s < c->mg_coarse_sweeps; ++s) {
-                hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[0], cur[0], om, oth[0]);
+                hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[0], cur[0], omc, oth[0]);
                 std::swap(cur[0], oth[0]);
             }
         } else {
-            hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(256), 0, st, op, rhs[nl - 1], om, c->mg_coarse_sweeps,
+            // the many sweeps of the coarsest solve use the mean damping (an undamped omega = 1 would leave
+            // the checkerboard mode untouched)
+            hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(256), 0, st, op, rhs[nl - 1], 0.5 * (om + om2), c->mg_coarse_sweeps,
                                cur[nl - 1], oth[nl - 1]);
         }
         CFD_HIP(hipGetLastError());

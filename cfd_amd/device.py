@@ -185,7 +185,7 @@ class Device:
         check(self.lib.cfd_set_solver(self._h, float(mom_tol), int(mom_maxiter), float(p_tol), int(p_maxiter),
                                       float(turb_tol), int(turb_maxiter), int(bool(freeze_pressure))))
 
-    def set_multigrid(self, nu_pre=2, nu_post=2, omega=0.8, coarse_sweeps=40, fused=True, omega2=0.0):
+    def set_multigrid(self, nu_pre=2, nu_post=2, omega=1.0, coarse_sweeps=40, fused=True, omega2=0.6):
         check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(omega), int(coarse_sweeps),
                                          int(bool(fused))))
         check(self.lib.cfd_set_smoother_omega2(self._h, float(omega2)))

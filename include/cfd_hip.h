@@ -171,10 +171,12 @@ int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, 
 /* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps; fused = 1 uses
  * the temporally blocked (two sweeps per pass) marching kernels when nu_pre = nu_post = 2  */
 int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused);
-/* Damping of the odd smoothing sweeps (the even ones use `omega` of cfd_set_multigrid).  omega = 0.5617,
- * omega2 = 1.3895 make two sweeps the degree-2 Chebyshev smoother on [0.5, 2] of the Jacobi-scaled
- * spectrum; omega2 <= 0 (default): plain damped Jacobi.  The single-block coarsest solve always uses
- * `omega`.  (Replaces pyamg's smoother choice, solver.py:821-833.)                                  */
+/* Damping of the odd smoothing sweeps (the even ones use `omega` of cfd_set_multigrid); the sweeps of one
+ * pass commute, so the preconditioner stays symmetric.  Defaults omega = 1.0, omega2 = 0.6: the smoothing
+ * factor of plain 0.8 / 0.8 on [0.5, 2] of the Jacobi-scaled spectrum (0.35) with a root at 1;
+ * omega = 0.5617, omega2 = 1.3895 would be the degree-2 Chebyshev smoother on that interval; omega2 <= 0:
+ * `omega` on every sweep.  The single-block coarsest solve uses the mean of the two.  (Replaces pyamg's
+ * smoother choice, solver.py:821-833.)                                                                  */
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
 /* Systems without any Dirichlet pressure (the reference pins one cell, solver.py:1033-1044):
  *   on = 1 (default): when the operator is symmetric the singular system is solved with every row kept
