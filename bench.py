@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--probe", type=int, default=0, help="kernel id for the live roofline probe")
+    ap.add_argument("--mg-sweeps", type=int, default=None, help="pre = post smoothing sweeps (2 or 3)")
+    ap.add_argument("--mg-omegas", type=str, default=None, help="comma-separated damping factors, used cyclically")
     ap.add_argument("--mg-omega", type=float, default=None, help="smoother damping of the even sweeps")
     ap.add_argument("--mg-omega2", type=float, default=None, help="smoother damping of the odd sweeps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -151,8 +153,13 @@ def main():
 
     n = args.size
     dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, world)
-    if args.mg_omega is not None or args.mg_omega2 is not None:
-        dev.set_multigrid(omega=args.mg_omega or 1.0, omega2=args.mg_omega2 if args.mg_omega2 is not None else 0.6)
+    if args.mg_sweeps is not None or args.mg_omegas is not None:
+        nu_s = args.mg_sweeps or 3
+        dev.set_multigrid(nu_pre=nu_s, nu_post=nu_s,
+                          omegas=[float(v) for v in args.mg_omegas.split(",")] if args.mg_omegas else None)
+    elif args.mg_omega is not None or args.mg_omega2 is not None:
+        dev.set_multigrid(nu_pre=2, nu_post=2, omega=args.mg_omega or 1.0,
+                          omega2=args.mg_omega2 if args.mg_omega2 is not None else 0.6)
     step = 0
     iters = []
     for _ in range(args.warmup):

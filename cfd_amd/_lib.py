@@ -69,6 +69,7 @@ SIGNATURES = {
     "cfd_set_multigrid": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]),
     "cfd_set_transport_solver": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_int]),
     "cfd_set_smoother_omega2": (C.c_int, [_vp, C.c_double]),
+    "cfd_set_smoother_omegas": (C.c_int, [_vp, C.c_int, _dp]),
     "cfd_set_flux_kernels": (C.c_int, [_vp, C.c_int, C.c_int]),
     "cfd_set_pressure_nullspace": (C.c_int, [_vp, C.c_int]),
     "cfd_set_turbulence_model": (C.c_int, [_vp, C.c_int]),

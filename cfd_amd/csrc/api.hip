@@ -251,6 +251,7 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, rank, min_slab_rows, c->l_agg, gs)
                                            : level_geometry(ni, nj);
     c->comm.rank = rank; c->comm.nranks = nranks; c->comm.nj_global = nj * nranks; c->comm.j_offset = rank * nj;
+    if (nranks > 1) { c->mg_pre = 2; c->mg_post = 2; c->mg_om[0] = 1.0; c->mg_om[1] = 0.6; c->mg_nom = 2; }
     c->g = lv[0];
     Carver cv{c->ws, 0, need};
     const size_t pb = c->g.plane_elems() * sizeof(double);
@@ -540,7 +541,8 @@ int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int c
     if (nu_pre < 1 || nu_post < 0 || !(omega > 0.0 && omega <= 1.0) || coarse_sweeps < 1) {
         set_error("cfd_set_multigrid: bad parameters"); return CFD_E_ARG;
     }
-    c->mg_pre = nu_pre; c->mg_post = nu_post; c->mg_omega = omega; c->mg_coarse_sweeps = coarse_sweeps;
+    c->mg_pre = nu_pre; c->mg_post = nu_post; c->mg_coarse_sweeps = coarse_sweeps;
+    c->mg_om[0] = omega; c->mg_nom = 1;          // cfd_set_smoother_omega2 / cfd_set_smoother_omegas extend the list
     return CFD_OK;
 }
 
@@ -558,7 +560,21 @@ int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2) {
     CTX_MUT(ctx);
     if (omega2 > 2.0) { set_error("cfd_set_smoother_omega2: omega2 must be <= 2"); return CFD_E_ARG; }
-    c->mg_omega2 = omega2;
+    if (omega2 > 0.0) { c->mg_om[1] = omega2; c->mg_nom = 2; } else c->mg_nom = 1;
+    return CFD_OK;
+}
+
+int cfd_set_smoother_omegas(cfd_ctx *ctx, int n, const double *omegas) {
+    CTX_MUT(ctx);
+    if (n < 1 || n > 4 || !omegas) { set_error("cfd_set_smoother_omegas: 1 to 4 values"); return CFD_E_ARG; }
+    double mean = 0.0;
+    for (int q = 0; q < n; ++q) {
+        if (!(omegas[q] > 0.0 && omegas[q] < 2.0)) { set_error("cfd_set_smoother_omegas: values must lie in (0, 2)"); return CFD_E_ARG; }
+        mean += omegas[q] / n;
+    }
+    if (!(mean <= 1.0)) { set_error("cfd_set_smoother_omegas: the mean damping must not exceed 1"); return CFD_E_ARG; }
+    for (int q = 0; q < n; ++q) c->mg_om[q] = omegas[q];
+    c->mg_nom = n;
     return CFD_OK;
 }
 

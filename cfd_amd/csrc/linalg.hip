@@ -876,14 +876,192 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df
     }
 }
 
-static inline bool level_fusable(const Ctx *c, const Geo &F, const Geo &C) {
-    return c->mg_fused && c->mg_pre == 2 && c->mg_post == 2 && F.ni >= 16 && F.nj >= 16 &&
-           C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
+// ---- K fused sweeps per pass (K = 3 on single-rank contexts: V(3,3) needs 5 PCG iterations at 8192^2
+// where V(2,2) needs 7, for the bytes of the two-sweep kernels).  Same structure as above with K halo
+// lanes / rows per side; stage s of row j runs while row j + s is being loaded.
+template <int K>
+struct SweepOm {
+    double w[K];
+};
+
+struct MgRaw {
+    double b, d, cw, ce, cs, cn, x, e;
+    int row;
+    bool valid;
+};
+
+template <bool UP>
+__device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, const Geo &g, const Geo &gc, const double *b,
+                                         const double *x, const double *e, int j, bool cvalid, size_t colo, size_t coloc,
+                                         MgRaw &R) {
+    const size_t P = g.pitch;
+    const int mr = mem_row(j, g, op.per_j);
+    R.valid = cvalid && mr >= 0;
+    const int js = (mr >= 0 ? mr : 2) - 2;
+    const size_t cc = (size_t)(js + 2) * P + colo;
+    if (UP) {
+        R.x = x[cc];
+        R.e = e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
+    }
+    R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+    R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+    R.d = (df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
+    R.row = (!df.on || mr == g.nj + 3) ? -1000000 : js;
 }
+__device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const OpDev &op, size_t colo) {
+    const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
+    return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
+}
+
+template <bool FINE, int K>
+__global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
+                                                   Geo gc, double *bc) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    constexpr int W = 64 - 2 * K;
+    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+        const int iraw = strip * W - K + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        // RC[s], V[s]: operator row / validity of row j - s;  X[s][0..2]: sweep s on rows (r - 2, r - 1, r), r = j - (s - 1)
+        RowC RC[K + 1];
+        bool V[K + 1];
+        double X[K + 1][3];
+#pragma unroll
+        for (int s2 = 0; s2 <= K; ++s2) {
+            RC[s2] = RowC{0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0};
+            V[s2] = false;
+            X[s2][0] = 0.0; X[s2][1] = 0.0; X[s2][2] = 0.0;
+        }
+        double rsum = 0.0;
+        MgRaw nxt;
+        mg_fetch<false>(op, df, g, gc, b, nullptr, nullptr, j0 - K, cvalid, colo, 0, nxt);
+        for (int j = j0 - K; j < j1 + K; ++j) {
+            const MgRaw cur = nxt;
+            if (j + 1 < j1 + K) mg_fetch<false>(op, df, g, gc, b, nullptr, nullptr, j + 1, cvalid, colo, 0, nxt);
+            RC[0] = mg_row(cur, df, op, colo);
+            V[0] = cur.valid;
+            X[1][2] = V[0] ? om.w[0] * RC[0].b * RC[0].inv : 0.0;          // first sweep from a zero guess
+#pragma unroll
+            for (int s2 = 2; s2 <= K; ++s2) {                               // sweep s2 on row j - (s2 - 1)
+                double xn = jac(X[s2 - 1][1], X[s2 - 1][0], X[s2 - 1][2], RC[s2 - 1], om.w[s2 - 1]);
+                if (!V[s2 - 1]) xn = 0.0;
+                X[s2][2] = xn;
+                if (s2 == K) {
+                    const int row = j - (K - 1);
+                    if (row >= j0 && row < j1 && out) x[(size_t)(row + 2) * P + colo] = xn;
+                }
+            }
+            // residual on row j - K, summed over 2 x 2 aggregates into the coarse right-hand side
+            const int jo = j - K;
+            const double res = resid(X[K][1], X[K][0], X[K][2], RC[K]);
+            if (jo >= j0 && jo < j1) {
+                rsum += res;
+                if (((jo - j0) & 1) || jo == j1 - 1) {
+                    const double tot = rsum + lane_right(rsum);
+                    if (out && !((lane - K) & 1)) bc[gc.cell(iraw >> 1, jo >> 1)] = (iraw + 1 < g.ni) ? tot : rsum;
+                    rsum = 0.0;
+                }
+            }
+#pragma unroll
+            for (int s2 = K; s2 >= 1; --s2) { RC[s2] = RC[s2 - 1]; V[s2] = V[s2 - 1]; }
+#pragma unroll
+            for (int s2 = 1; s2 <= K; ++s2) { X[s2][0] = X[s2][1]; X[s2][1] = X[s2][2]; }
+        }
+    }
+}
+
+template <bool FINE, int K>
+__global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
+                                                 const double *e, double gamma, SweepOm<K> om, double *xn, double *partials) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    constexpr int W = 64 - 2 * K;
+    double dot = 0.0;
+    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+        const int iraw = strip * W - K + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + 2;
+        const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        // RC[s], V[s]: row j - s;  X[s][0..2]: iterate after s sweeps on rows (r - 2, r - 1, r), r = j - s
+        RowC RC[K + 1];
+        bool V[K + 1];
+        double X[K + 1][3];
+#pragma unroll
+        for (int s2 = 0; s2 <= K; ++s2) {
+            RC[s2] = RowC{0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0};
+            V[s2] = false;
+            X[s2][0] = 0.0; X[s2][1] = 0.0; X[s2][2] = 0.0;
+        }
+        MgRaw nxt;
+        mg_fetch<true>(op, df, g, gc, b, x, e, j0 - K, cvalid, colo, coloc, nxt);
+        for (int j = j0 - K; j < j1 + K; ++j) {
+            const MgRaw cur = nxt;
+            if (j + 1 < j1 + K) mg_fetch<true>(op, df, g, gc, b, x, e, j + 1, cvalid, colo, coloc, nxt);
+            RC[0] = mg_row(cur, df, op, colo);
+            V[0] = cur.valid;
+            X[0][2] = cur.valid ? cur.x + gamma * cur.e : 0.0;              // prolongated iterate on row j
+#pragma unroll
+            for (int s2 = 1; s2 <= K; ++s2) {                               // sweep s2 on row j - s2
+                double v = jac(X[s2 - 1][1], X[s2 - 1][0], X[s2 - 1][2], RC[s2], om.w[s2 - 1]);
+                if (!V[s2]) v = 0.0;
+                X[s2][2] = v;
+                if (s2 == K) {
+                    const int row = j - K;
+                    if (row >= j0 && row < j1 && out) {
+                        xn[(size_t)(row + 2) * P + colo] = v;
+                        if (FINE) dot += RC[K].b * v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s2 = K; s2 >= 1; --s2) { RC[s2] = RC[s2 - 1]; V[s2] = V[s2 - 1]; }
+#pragma unroll
+            for (int s2 = 0; s2 <= K; ++s2) { X[s2][0] = X[s2][1]; X[s2][1] = X[s2][2]; }
+        }
+    }
+    if (FINE) {
+        __shared__ double sm[4];
+        const double w = wsum(dot);
+        if (lane == 0) sm[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    }
+}
+
+// fused marching kernels: two sweeps per pass anywhere, three on single-rank contexts (a slab cut carries two halo rows)
+static inline bool level_fusable(const Ctx *c, const Geo &F, const Geo &C) {
+    const bool k_ok = c->mg_pre == c->mg_post && (c->mg_pre == 2 || (c->mg_pre == 3 && c->comm.nranks == 1));
+    return c->mg_fused && k_ok && F.ni >= 16 && F.nj >= 16 && C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
+}
+static inline MarchGeo march_geo_k(const Geo &g, int K);
 static inline int march_blocks(const MarchGeo &m) {
     const long items = (long)m.nstrips * m.nsegs;
     const long nb = (items + 3) / 4;
     return (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
+}
+// K halo lanes / rows per side: narrower strips, longer segments to amortise the 2K extra rows
+static inline MarchGeo march_geo_k(const Geo &g, int K) {
+    if (K <= 2) return march_geo(g);
+    MarchGeo m;
+    m.nstrips = (g.ni + (64 - 2 * K) - 1) / (64 - 2 * K);
+    int Ls = 64;
+    while (Ls > 8 && (long)m.nstrips * ((g.nj + Ls - 1) / Ls) < 8192) Ls /= 2;
+    m.Ls = Ls;
+    m.nsegs = (g.nj + Ls - 1) / Ls;
+    return m;
 }
 
 // ------------------------------------------------------------------ Chebyshev (time-step dominated systems)
@@ -1613,8 +1791,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     const int nl = (int)c->levels.size();
     // sweep s of a smoothing pass uses omega (even s) or omega2 (odd s): with omega2 != omega the two
     // sweeps form the degree-2 Chebyshev polynomial smoother on the upper part of the Jacobi spectrum
-    const double om = c->mg_omega, om2 = c->mg_omega2 > 0.0 ? c->mg_omega2 : c->mg_omega;
+    const double om = c->om_at(0), om2 = c->om_at(1);
     const int pre = c->mg_pre < 1 ? 1 : c->mg_pre, post = c->mg_post;
+    const int KS = pre;                          // sweeps fused per pass where level_fusable()
+    SweepOm<3> om3{{c->om_at(0), c->om_at(1), c->om_at(2)}};
     std::vector<double *> cur(nl), oth(nl);
     std::vector<const double *> rhs(nl);
     for (int l = 0; l < nl; ++l) {
@@ -1635,13 +1815,18 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         const Geo cg = coarse_view(c, l + 1);
         double *cb = to_agg ? C.s0 : C.b;
         if (level_fusable(c, L.g, cg)) {
-            const MarchGeo mgeo = march_geo(L.g);
+            const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
             CFD_TRY(halo_exchange(c, L.g, 2, const_cast<double *>(rhs[l])));
             if (l == 0) {
                 c->probe_begin(1);
-                hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
+                if (KS == 3)
+                    hipLaunchKernelGGL((k_mg_down_k<true, 3>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb);
+                else
+                    hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
                 c->probe_end(1);
+            } else if (KS == 3) {
+                hipLaunchKernelGGL((k_mg_down_k<false, 3>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb);
             } else {
                 hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om, om2, cur[l], cg, cb);
             }
@@ -1651,7 +1836,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
             for (int s = 1; s < pre; ++s) {
                 CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
-                hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], (s & 1) ? om2 : om, oth[l]);
+                hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], c->om_at(s), oth[l]);
                 std::swap(cur[l], oth[l]);
             }
             CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
@@ -1669,7 +1854,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (nl == 1) {
             // single-level "hierarchy": plain Jacobi sweeps
             const Tiling T = tiling(L.g);
-            const double omc = 0.5 * (om + om2);
+            const double omc = c->om_mean();
             hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[0], omc, cur[0]);
             for (int s = 1; s < c->mg_coarse_sweeps; ++s) {
                 hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[0], cur[0], omc, oth[0]);
@@ -1678,7 +1863,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         } else {
             // the many sweeps of the coarsest solve use the mean damping (an undamped omega = 1 would leave
             // the checkerboard mode untouched)
-            hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(256), 0, st, op, rhs[nl - 1], 0.5 * (om + om2), c->mg_coarse_sweeps,
+            hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(256), 0, st, op, rhs[nl - 1], c->om_mean(), c->mg_coarse_sweeps,
                                cur[nl - 1], oth[nl - 1]);
         }
         CFD_HIP(hipGetLastError());
@@ -1695,15 +1880,22 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
         else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, 1, cur[l + 1]));
         if (level_fusable(c, L.g, cg)) {
-            const MarchGeo mgeo = march_geo(L.g);
+            const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
             CFD_TRY(halo_exchange(c, L.g, 2, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
-                hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
-                                   oth[l], c->partials);
+                if (KS == 3)
+                    hipLaunchKernelGGL((k_mg_up_k<true, 3>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
+                                       om3, oth[l], c->partials);
+                else
+                    hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
+                                       oth[l], c->partials);
                 c->probe_end(7);
                 *dot_blocks = (int)grid.x;
+            } else if (KS == 3) {
+                hipLaunchKernelGGL((k_mg_up_k<false, 3>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
+                                   oth[l], c->partials);
             } else {
                 hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);
@@ -1718,7 +1910,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, cg, fi, fj, e, c->mg_gamma, cur[l]);
         for (int s = 0; s < post; ++s) {
             CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
-            hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], (s & 1) ? om2 : om, oth[l]);
+            hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], c->om_at(s), oth[l]);
             std::swap(cur[l], oth[l]);
         }
         CFD_HIP(hipGetLastError());
@@ -2123,9 +2315,9 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                     if (c->levels.size() > 1 && level_fusable(c, c->levels[0].g, coarse_view(c, 1))) {
                         const MarchGeo mgeo = march_geo(g);
                         hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->p_diag, c->kry[1],
-                                           c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_gamma, c->mg_omega, c->mg_omega, c->kry[5], c->partials);
+                                           c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_gamma, c->om_at(0), c->om_at(1), c->kry[5], c->partials);
                     } else {
-                        hipLaunchKernelGGL(k_mg_jacobi, grid, blk, 0, st, op, T, c->kry[1], c->kry[4], c->mg_omega, c->kry[5]);
+                        hipLaunchKernelGGL(k_mg_jacobi, grid, blk, 0, st, op, T, c->kry[1], c->kry[4], c->om_at(0), c->kry[5]);
                     }
                     break;
                 }

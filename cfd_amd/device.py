@@ -185,10 +185,18 @@ class Device:
         check(self.lib.cfd_set_solver(self._h, float(mom_tol), int(mom_maxiter), float(p_tol), int(p_maxiter),
                                       float(turb_tol), int(turb_maxiter), int(bool(freeze_pressure))))
 
-    def set_multigrid(self, nu_pre=2, nu_post=2, omega=1.0, coarse_sweeps=40, fused=True, omega2=0.6):
-        check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(omega), int(coarse_sweeps),
+    def set_multigrid(self, nu_pre=3, nu_post=3, omega=None, coarse_sweeps=40, fused=True, omega2=None, omegas=None):
+        """omegas: list of 1-4 Jacobi damping factors used cyclically by the sweeps (default (1.0, 0.55, 0.9));
+        omega / omega2: the older two-value form."""
+        if omegas is None:
+            if omega is None:
+                omegas = (1.0, 0.55, 0.9) if nu_pre == 3 and self.nranks == 1 else (1.0, 0.6)
+            else:
+                omegas = (omega,) if not omega2 else (omega, omega2)
+        om = np.ascontiguousarray(omegas, dtype=np.float64)
+        check(self.lib.cfd_set_multigrid(self._h, int(nu_pre), int(nu_post), float(min(om[0], 1.0)), int(coarse_sweeps),
                                          int(bool(fused))))
-        check(self.lib.cfd_set_smoother_omega2(self._h, float(omega2)))
+        check(self.lib.cfd_set_smoother_omegas(self._h, int(om.size), dptr(om)))
 
     def set_transport_solver(self, warm_start=True, chebyshev=True, rho_max=0.95, max_iters=80):
         check(self.lib.cfd_set_transport_solver(self._h, int(bool(warm_start)), int(bool(chebyshev)), float(rho_max),

@@ -169,7 +169,8 @@ int cfd_set_physics(cfd_ctx *ctx, double nu, double dpdx, double dpdy, int rhie_
 int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, int p_maxiter,
                    double turb_tol, int turb_maxiter, int freeze_pressure);
 /* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps; fused = 1 uses
- * the temporally blocked (two sweeps per pass) marching kernels when nu_pre = nu_post = 2  */
+ * the temporally blocked marching kernels (all sweeps of a pass in one kernel) when
+ * nu_pre = nu_post = 2, or 3 on single-rank contexts                                        */
 int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused);
 /* Damping of the odd smoothing sweeps (the even ones use `omega` of cfd_set_multigrid); the sweeps of one
  * pass commute, so the preconditioner stays symmetric.  Defaults omega = 1.0, omega2 = 0.6: the smoothing
@@ -178,6 +179,10 @@ int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int c
  * `omega` on every sweep.  The single-block coarsest solve uses the mean of the two.  (Replaces pyamg's
  * smoother choice, solver.py:821-833.)                                                                  */
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
+/* General form: n = 1..4 damping factors in (0, 2), mean <= 1, used cyclically by the sweeps of a pass.
+ * Defaults: single-rank contexts V(3,3) with (1.0, 0.55, 0.9) (three sweeps fused per pass: 5 MG-PCG
+ * iterations per solve at 8192^2), j-slab contexts V(2,2) with (1.0, 0.6) (a cut carries two halo rows).  */
+int cfd_set_smoother_omegas(cfd_ctx *ctx, int n, const double *omegas);
 /* Systems without any Dirichlet pressure (the reference pins one cell, solver.py:1033-1044):
  *   on = 1 (default): when the operator is symmetric the singular system is solved with every row kept
  *   (right-hand side made compatible at the reference cell's row, the row the reference drops) and the

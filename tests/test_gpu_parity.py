@@ -332,9 +332,10 @@ def _bc_variant(kind, ni, nj):
             "j_min": wall_j, "j_max": wall_j, "pressure_reference": {"cell": (0, 0), "value": 0.0}}
 
 
+@pytest.mark.parametrize("sweeps,omegas", [(2, (0.8,)), (2, (1.0, 0.6)), (3, (1.0, 0.55, 0.9))])
 @pytest.mark.parametrize("kind,ni,nj", [("per_i", 64, 48), ("per_i", 130, 67), ("per_j", 33, 40), ("inout", 50, 37),
                                          ("inout", 257, 129)])
-def test_fused_vcycle_matches_unfused(kind, ni, nj):
+def test_fused_vcycle_matches_unfused(kind, ni, nj, sweeps, omegas):
     """The temporally blocked marching kernels (two Jacobi sweeps per pass, residual+restrict and
     prolongation folded in) compute the same V-cycle as the one-kernel-per-sweep path."""
     mesh = orc.rect_mesh(2.0, 1.0, ni, nj, 1.0, 1.0 + 1.6 / nj)      # max/min dy ~ 5 (point smoother regime)
@@ -347,15 +348,15 @@ def test_fused_vcycle_matches_unfused(kind, ni, nj):
     per_i, per_j = kind == "per_i", kind == "per_j"
     a = orc.five_point_matrix(diag, ci[:-1], ci[1:], cj[:, :-1], cj[:, 1:], per_i, per_j)
     r = rng.standard_normal((ni, nj))
-    dev.set_multigrid(2, 2, 0.8, 40, fused=False)
+    dev.set_multigrid(sweeps, sweeps, coarse_sweeps=40, fused=False, omegas=omegas)
     z_ref = dev.vcycle(r)
-    dev.set_multigrid(2, 2, 0.8, 40, fused=True)
+    dev.set_multigrid(sweeps, sweeps, coarse_sweeps=40, fused=True, omegas=omegas)
     z = dev.vcycle(r)
     assert rel_l2(z, z_ref) < 1e-12
     x_true = rng.standard_normal((ni, nj))
     b = a.dot(x_true.ravel()).reshape(ni, nj)
     for fused in (False, True):
-        dev.set_multigrid(2, 2, 0.8, 40, fused=fused)
+        dev.set_multigrid(sweeps, sweeps, coarse_sweeps=40, fused=fused, omegas=omegas)
         sol, iters, relres = dev.pressure_krylov(b, tol=1e-12, maxiter=300)
         assert relres <= 1e-12 and iters < 80, (fused, iters, relres)
         assert np.linalg.norm((a.dot(sol.ravel()) - b.ravel())) <= 1e-10 * np.linalg.norm(b.ravel())
