@@ -1450,7 +1450,8 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         }
         ChebStages<K> cf;
         for (int s2 = 0; s2 < K; ++s2) cc.next(cf.c1[s2], cf.c2[s2]);
-        c->probe_begin(8);
+        const int probe_id = (na == 2) ? 8 : 9;      // 8: both right-hand sides in the launch, 9: one
+        c->probe_begin(probe_id);
         if (na == NB) {
             CVecs<NB> xk, xm;
             Vecs<NB> o1, o2;
@@ -1474,7 +1475,7 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             else
                 hipLaunchKernelGGL((k_chebk<1, K>), grid, dim3(256), 0, st, op, mgeo, cf, 0, b1, xk, xm, o1, o2, c->partials);
         }
-        c->probe_end(8);
+        c->probe_end(probe_id);
         CFD_HIP(hipGetLastError());
         const int k0 = K * (m - 1);                // this launch measured |r_k0| and |r_{k0+K-1}|
         int kmin = 1 << 30;

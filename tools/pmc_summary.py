@@ -16,7 +16,7 @@ from collections import defaultdict
 tag = sys.argv[1]
 cells = float(sys.argv[2]) if len(sys.argv) > 2 else 8192.0 * 8192.0
 # algorithmic bytes per cell and launch
-ALGO = {"k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 64, "k_mg_up<true>": 42, "k_mg_down<true>": 34, "k_cg_r": 24, "k_cg_init": 24,
+ALGO = {"k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 64, "k_mg_up<true>": 42, "k_mg_down<true>": 34, "k_mg_up_k<true, 3>": 42, "k_mg_down_k<true, 3>": 34, "k_cg_r": 24, "k_cg_init": 24,
         "k_cg_xlast": 24, "k_flux_march<0, false>": 104, "k_flux_march<1, false>": 112, "k_flux_march<2, false>": 120,
         "k_continuity": 104, "k_pressure_rhs": 112, "k_momentum_rhs": 120, "k_correct": 136, "k_diffusion_ap": 88,
         "k_dt": 88, "k_rowsum_bound": 24, "k_pressure_coeffs": 64}
