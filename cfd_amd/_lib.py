@@ -18,6 +18,7 @@ F_U, F_V, F_P, F_K, F_OMEGA, F_NUT, F_PCORR, F_AP, F_AI, F_AJ, F_BU, F_BV = rang
 F_SST_S, F_SST_F1, F_SST_F2, F_SST_DK, F_SST_DW, F_SST_DWALL = range(12, 18)
 TURB_KOMEGA, TURB_SST = 0, 1
 KIND_GHOSTED, KIND_CELL, KIND_FACE_I, KIND_FACE_J = range(4)
+GHOST_ROWS = 4          # CFD_GHOST_ROWS of include/cfd_hip.h (checked against cfd_ghost_rows() when the library loads)
 SIDE_IMIN, SIDE_IMAX, SIDE_JMIN, SIDE_JMAX = range(4)
 SIDES = {"i_min": 0, "i_max": 1, "j_min": 2, "j_max": 3}
 BC_NONE, BC_AFFINE, BC_SYMMETRY, BC_PERIODIC = range(4)
@@ -51,6 +52,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "cfd_last_error": (C.c_char_p, []),
     "cfd_version": (C.c_int, []),
+    "cfd_ghost_rows": (C.c_int, []),
     "cfd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "cfd_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]),
     "cfd_destroy": (C.c_int, [_vp]),
@@ -140,6 +142,8 @@ def load():
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.cfd_ghost_rows() != GHOST_ROWS:
+        raise HipError(f"libcfd_hip.so uses {lib.cfd_ghost_rows()} ghost rows, cfd_amd._lib expects {GHOST_ROWS}")
     _lib = lib
     return lib
 

@@ -196,6 +196,7 @@ extern "C" {
 
 const char *cfd_last_error(void) { return cfd::g_err; }
 int cfd_version(void) { return 100; }
+int cfd_ghost_rows(void) { return cfd::NG; }
 
 size_t cfd_workspace_bytes(int ni, int nj) {
     if (ni < 1 || nj < 1) return 0;
@@ -251,7 +252,6 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, rank, min_slab_rows, c->l_agg, gs)
                                            : level_geometry(ni, nj);
     c->comm.rank = rank; c->comm.nranks = nranks; c->comm.nj_global = nj * nranks; c->comm.j_offset = rank * nj;
-    if (nranks > 1) { c->mg_pre = 2; c->mg_post = 2; c->mg_om[0] = 1.0; c->mg_om[1] = 0.6; c->mg_nom = 2; }
     c->g = lv[0];
     Carver cv{c->ws, 0, need};
     const size_t pb = c->g.plane_elems() * sizeof(double);

@@ -13,7 +13,7 @@ static int need_comm(const Ctx *c, const void *fn, const char *what) {
 int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b, double *d, double *e) {
     if (c->comm.nranks <= 1 || !(g.cutlo || g.cuthi)) return CFD_OK;
     CFD_TRY(need_comm(c, (const void *)c->comm.halo, "halo"));
-    if (depth < 1 || depth > 2 || depth > g.nj) { set_error("halo depth %d not possible on %d rows", depth, g.nj); return CFD_E_ARG; }
+    if (depth < 1 || depth > NG || depth > g.nj) { set_error("halo depth %d not possible on %d rows", depth, g.nj); return CFD_E_ARG; }
     double *pl[4] = {a, b, d, e};
     int n = 0;
     while (n < 4 && pl[n]) ++n;

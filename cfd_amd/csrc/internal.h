@@ -23,6 +23,11 @@ constexpr double OMEGA_FLOOR = 1.0e-6;   // turbulence.py:29
 constexpr int MAX_PARTIALS = 4096;
 constexpr int MAX_LEVELS = 24;
 
+// ghost rows below and above the interior of every plane: the inner one is the reference's ghost layer, the
+// others are halo rows of the fused kernels (three smoothing sweeps, four Chebyshev iterations per pass) and of
+// the j-slab exchange.  Plane row r holds j = r - NG.
+constexpr int NG = CFD_GHOST_ROWS;
+
 struct Geo {
     int ni, nj, pitch;
     // j-slab decomposition: cutlo / cuthi = 1 when the low / high j edge of this slab is a cut
@@ -34,9 +39,9 @@ struct Geo {
     // two ghost rows below and above the interior (rows -2, -1 and nj, nj+1): the inner pair is the
     // reference's ghost layer, the outer pair is the extra halo row of the two-sweep fused kernels
     // and of the j-slab exchange.  ghosted index jg = j + 1.
-    __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)(jg + 1) * pitch + ig + 1; }
-    __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + 2) * pitch + i + 2; }
-    __host__ inline size_t plane_elems() const { return (size_t)(nj + 4) * pitch; }
+    __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)(jg + NG - 1) * pitch + ig + 1; }
+    __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + NG) * pitch + i + 2; }
+    __host__ inline size_t plane_elems() const { return (size_t)(nj + 2 * NG) * pitch; }
 };
 
 inline int pitch_for(int ni) { return ((ni + 4) + 31) / 32 * 32; }

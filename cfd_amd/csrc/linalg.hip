@@ -607,13 +607,13 @@ __device__ __forceinline__ int wrap_index(int v, int n, int per) {
     v %= n;
     return v < 0 ? v + n : v;
 }
-// plane row (= j + 2) that holds logical row j, or -1 when the row lies outside the domain.
+// plane row (= j + NG) that holds logical row j, or -1 when the row lies outside the domain.
 // Rows leave the slab by at most two cells: across a slab cut they are the halo rows, across a
 // periodic seam one conditional add / subtract wraps them.
 __device__ __forceinline__ int mem_row(int j, const Geo &g, int per) {
-    if (j >= 0 && j < g.nj) return j + 2;
-    if (j < 0) return g.cutlo ? j + 2 : (per ? j + g.nj + 2 : -1);
-    return g.cuthi ? j + 2 : (per ? j - g.nj + 2 : -1);
+    if (j >= 0 && j < g.nj) return j + NG;
+    if (j < 0) return g.cutlo ? j + NG : (per ? j + g.nj + NG : -1);
+    return g.cuthi ? j + NG : (per ? j - g.nj + NG : -1);
 }
 
 // 1/d without the IEEE division sequence: v_rcp_f64 + two Newton steps (the V-cycle is a
@@ -707,13 +707,13 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, DiagFix 
         auto fetch = [&](int j, Raw &R) {
             const int mr = mem_row(j, g, op.per_j);
             R.valid = cvalid && mr >= 0;
-            R.row = (mr >= 0 ? mr : 2) - 2;
-            const size_t cc = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+            R.row = (mr >= 0 ? mr : NG) - NG;
+            const size_t cc = (size_t)(mr >= 0 ? mr : NG) * P + colo;
             R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
-            R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+            R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
             // the outermost halo row of a high slab cut has no north face in memory: its D is read
-            R.d = (df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
-            if (!df.on || mr == g.nj + 3) R.row = -1000000;
+            R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
+            if (!df.on || mr == g.nj + 2 * NG - 1) R.row = -1000000;
         };
         auto mk = [&](const Raw &R) -> RowC {
             const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, DiagFix 
                 // second sweep on row j-1
                 x2c = jac(x1b, x1a, x1c, rc1, omega2);
                 if (!v1) x2c = 0.0;                   // outside the domain: x = 0
-                if (j - 1 >= j0 && j - 1 < j1 && out) x[(size_t)(j + 1) * P + colo] = x2c;
+                if (j - 1 >= j0 && j - 1 < j1 && out) x[(size_t)(j - 1 + NG) * P + colo] = x2c;
                 // residual on row j-2
                 const int jo = j - 2;
                 const double res = resid(x2b, x2a, x2c, rc2);
@@ -801,14 +801,14 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df
         auto fetch = [&](int j, Raw &R) {
             const int mr = mem_row(j, g, op.per_j);
             R.valid = cvalid && mr >= 0;
-            const int js = (mr >= 0 ? mr : 2) - 2;     // -2, -1 / nj, nj+1 are halo rows at a slab cut
-            const size_t cc = (size_t)(js + 2) * P + colo;
+            const int js = (mr >= 0 ? mr : NG) - NG;     // -2, -1 / nj, nj+1 are halo rows at a slab cut
+            const size_t cc = (size_t)(js + NG) * P + colo;
             R.x = x[cc];
-            R.e = e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
+            R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
             R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
-            R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
-            R.d = (df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
-            R.row = (!df.on || mr == g.nj + 3) ? -1000000 : js;
+            R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
+            R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
+            R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
         };
         auto mk = [&](const Raw &R) -> RowC {
             const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df
                 const int jo = j - 2;
                 const double x2 = jac(x1b, x1a, x1c, rc2, omega2);
                 if (jo >= j0 && jo < j1 && out) {
-                    xn[(size_t)(jo + 2) * P + colo] = x2;
+                    xn[(size_t)(jo + NG) * P + colo] = x2;
                     if (FINE) dot += rc2.b * x2;
                 }
                 x0a = x0b; x0b = x0c;
@@ -897,16 +897,16 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
     const size_t P = g.pitch;
     const int mr = mem_row(j, g, op.per_j);
     R.valid = cvalid && mr >= 0;
-    const int js = (mr >= 0 ? mr : 2) - 2;
-    const size_t cc = (size_t)(js + 2) * P + colo;
+    const int js = (mr >= 0 ? mr : NG) - NG;
+    const size_t cc = (size_t)(js + NG) * P + colo;
     if (UP) {
         R.x = x[cc];
-        R.e = e[(size_t)((js >> 1) + 2) * gc.pitch + coloc];
+        R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
     R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
-    R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
-    R.d = (df.on && mr != g.nj + 3) ? 0.0 : op.D[cc];
-    R.row = (!df.on || mr == g.nj + 3) ? -1000000 : js;
+    R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
+    R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
+    R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
 }
 __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const OpDev &op, size_t colo) {
     const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFi
                 X[s2][2] = xn;
                 if (s2 == K) {
                     const int row = j - (K - 1);
-                    if (row >= j0 && row < j1 && out) x[(size_t)(row + 2) * P + colo] = xn;
+                    if (row >= j0 && row < j1 && out) x[(size_t)(row + NG) * P + colo] = xn;
                 }
             }
             // residual on row j - K, summed over 2 x 2 aggregates into the coarse right-hand side
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix 
                 if (s2 == K) {
                     const int row = j - K;
                     if (row >= j0 && row < j1 && out) {
-                        xn[(size_t)(row + 2) * P + colo] = v;
+                        xn[(size_t)(row + NG) * P + colo] = v;
                         if (FINE) dot += RC[K].b * v;
                     }
                 }
@@ -1041,9 +1041,9 @@ __global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix 
     }
 }
 
-// fused marching kernels: two sweeps per pass anywhere, three on single-rank contexts (a slab cut carries two halo rows)
+// fused marching kernels: two or three sweeps per pass (a slab cut carries NG = 4 halo rows)
 static inline bool level_fusable(const Ctx *c, const Geo &F, const Geo &C) {
-    const bool k_ok = c->mg_pre == c->mg_post && (c->mg_pre == 2 || (c->mg_pre == 3 && c->comm.nranks == 1));
+    const bool k_ok = c->mg_pre == c->mg_post && (c->mg_pre == 2 || c->mg_pre == 3);
     return c->mg_fused && k_ok && F.ni >= 16 && F.nj >= 16 && C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
 }
 static inline MarchGeo march_geo_k(const Geo &g, int K);
@@ -1162,8 +1162,8 @@ __global__ __launch_bounds__(256) void k_cheb2(OpDev op, MarchGeo mg, double c1a
         auto load = [&](int j, bool &valid, RowA &a, double (&xv)[NB]) -> size_t {
             const int mr = mem_row(j, g, op.per_j);
             valid = cvalid && mr >= 0;
-            const size_t c = (size_t)(mr >= 0 ? mr : 2) * P + colo;
-            a.d = op.D[c]; a.cw = op.ci[c]; a.ce = op.ci[c + 1]; a.cs = op.cj[c]; a.cn = op.cj[c + (mr < g.nj + 3 ? P : 0)];
+            const size_t c = (size_t)(mr >= 0 ? mr : NG) * P + colo;
+            a.d = op.D[c]; a.cw = op.ci[c]; a.ce = op.ci[c + 1]; a.cs = op.cj[c]; a.cn = op.cj[c + (mr < g.nj + 2 * NG - 1 ? P : 0)];
             a.inv = fast_rcp(a.d);
 #pragma unroll
             for (int q = 0; q < NB; ++q) xv[q] = valid ? xk.p[q][c] : 0.0;
@@ -1226,8 +1226,8 @@ __global__ __launch_bounds__(256) void k_cheb2(OpDev op, MarchGeo mg, double c1a
 // x_{k-1}, b, D, c_i, c_j are still read once and x_{k+K-1}, x_{k+K} written, so the 104 B buy K
 // iterations.  Stage s (1..K) produces iterate k+s on row j-s while row j is being loaded; |r_k|^2 and
 // |r_{k+K-1}|^2 (the residuals of the two iterates that exist in memory afterwards) are the partial
-// sums [q] and [NB + q], |b|^2 is [2 NB + q] on the first launch.  Single-slab contexts only: a slab
-// cut carries two halo rows, not K.
+// sums [q] and [NB + q], |b|^2 is [2 NB + q] on the first launch.  At a slab cut the K halo rows come
+// from the neighbour (K <= NG).
 template <int K>
 struct ChebStages {
     double c1[K], c2[K];
@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
         size_t CELL[K + 1];
 #pragma unroll
         for (int s2 = 0; s2 <= K; ++s2) {
-            V[s2] = false; CELL[s2] = 2 * P + colo;
+            V[s2] = false; CELL[s2] = NG * P + colo;
             RA[s2] = RowA{1.0, 1.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < NB; ++q) { X[s2][0][q] = 0.0; X[s2][1][q] = 0.0; X[s2][2][q] = 0.0; B[s2][q] = 0.0; }
@@ -1273,10 +1273,10 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
         auto fetch = [&](int j, RowIn &R) {
             const int mr = mem_row(j, g, op.per_j);
             R.valid = cvalid && mr >= 0;
-            const size_t c = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+            const size_t c = (size_t)(mr >= 0 ? mr : NG) * P + colo;
             R.cell = c;
             R.d = op.D[c]; R.cw = op.ci[c]; R.ce = op.ci[c + 1]; R.cs = op.cj[c];
-            R.cn = op.cj[c + (mr < g.nj + 3 ? P : 0)];
+            R.cn = op.cj[c + (mr < g.nj + 2 * NG - 1 ? P : 0)];
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 R.x[q] = xk.p[q][c];
@@ -1410,10 +1410,10 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         set[0][1][q] = c->kry[9 + q];
     }
     if (c->comm.nranks > 1) {
-        // the two fused iterations read two rows across a cut
-        CFD_TRY(halo_exchange(c, g, 2, const_cast<double *>(op.ci), const_cast<double *>(op.cj), const_cast<double *>(op.D)));
-        CFD_TRY(halo_exchange(c, g, 1, b[0], NB == 2 ? b[NB - 1] : nullptr));
-        CFD_TRY(halo_exchange(c, g, 2, const_cast<double *>(x0[0]), NB == 2 ? const_cast<double *>(x0[NB - 1]) : nullptr));
+        // the K fused iterations read K rows across a cut
+        CFD_TRY(halo_exchange(c, g, K, const_cast<double *>(op.ci), const_cast<double *>(op.cj), const_cast<double *>(op.D)));
+        CFD_TRY(halo_exchange(c, g, K - 1, b[0], NB == 2 ? b[NB - 1] : nullptr));
+        CFD_TRY(halo_exchange(c, g, K, const_cast<double *>(x0[0]), NB == 2 ? const_cast<double *>(x0[NB - 1]) : nullptr));
     }
     const double rho = -c->h_scal[12];
     ChebCoef cc(rho);
@@ -1444,9 +1444,9 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             cur_m[q] = m == 1 ? const_cast<double *>(x0[q]) : set[(m - 1) & 1][0][q];
         }
         if (m > 1 && c->comm.nranks > 1) {
-            // x_k needs two rows, x_{k-1} one: a single message set of depth 2 for all of them
-            if (na == 2) CFD_TRY(halo_exchange(c, g, 2, cur_k[0], cur_k[1], cur_m[0], cur_m[1]));
-            else CFD_TRY(halo_exchange(c, g, 2, cur_k[qs[0]], cur_m[qs[0]]));
+            // x_k needs K rows, x_{k-1} K - 1: a single message set of depth K for all of them
+            if (na == 2) CFD_TRY(halo_exchange(c, g, K, cur_k[0], cur_k[1], cur_m[0], cur_m[1]));
+            else CFD_TRY(halo_exchange(c, g, K, cur_k[qs[0]], cur_m[qs[0]]));
         }
         ChebStages<K> cf;
         for (int s2 = 0; s2 < K; ++s2) cc.next(cf.c1[s2], cf.c2[s2]);
@@ -1551,7 +1551,7 @@ static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double 
         if (op.D == c->ap && c->ap_cached) c->rho_cached = rho_f;
         if (!(rho_f >= 0.0) || rho_f > c->cheb_rho_max) return CFD_OK;
         // four iterations per launch where no slab cut limits the halo depth to two rows
-        if (c->comm.nranks == 1 && c->cheb_stages >= 4 && g.ni >= 64 && g.nj >= 64)
+        if (c->cheb_stages >= 4 && g.ni >= 64 && g.nj >= 64)
             return chebyshev_fused<NB, 4>(c, op, b, x, x0, tol, maxiter, iters, relres, rms, used);
         return chebyshev_fused<NB, 2>(c, op, b, x, x0, tol, maxiter, iters, relres, rms, used);
     }
@@ -1753,7 +1753,9 @@ int build_pressure_hierarchy(Ctx *c) {
         c->p_diag = f;
     }
     const int la = c->l_agg;
-    CFD_TRY(halo_exchange(c, L0.g, 2, L0.ci, L0.cj, L0.D));
+    // the fused kernels read K halo rows of the operator, and the diagonal recomputed from the faces needs the
+    // north face of the outermost of them: all NG rows
+    CFD_TRY(halo_exchange(c, L0.g, NG, L0.ci, L0.cj, L0.D));
     for (int l = 0; l + 1 < (int)c->levels.size(); ++l) {
         Level &F = c->levels[l], &C = c->levels[l + 1];
         const bool to_agg = la > 0 && l + 1 == la;
@@ -1771,14 +1773,14 @@ int build_pressure_hierarchy(Ctx *c) {
             // replicate the level: every rank gathers all slabs, the top boundary face row of c_j
             // comes from the last rank (gathered through the scratch plane)
             const size_t P = cg.pitch, rows = (size_t)cg.nj * P;
-            CFD_TRY(all_gather_rows(c, ci_t + 2 * P, C.ci + 2 * P, rows));
-            CFD_TRY(all_gather_rows(c, cj_t + 2 * P, C.cj + 2 * P, rows));
-            CFD_TRY(all_gather_rows(c, D_t + 2 * P, C.D + 2 * P, rows));
-            CFD_TRY(all_gather_rows(c, cj_t + (size_t)(2 + cg.nj) * P, C.t + 2 * P, P));
-            CFD_HIP(hipMemcpyAsync(C.cj + (size_t)(2 + C.g.nj) * P, C.t + (size_t)(2 + c->comm.nranks - 1) * P,
+            CFD_TRY(all_gather_rows(c, ci_t + NG * P, C.ci + NG * P, rows));
+            CFD_TRY(all_gather_rows(c, cj_t + NG * P, C.cj + NG * P, rows));
+            CFD_TRY(all_gather_rows(c, D_t + NG * P, C.D + NG * P, rows));
+            CFD_TRY(all_gather_rows(c, cj_t + (size_t)(NG + cg.nj) * P, C.t + NG * P, P));
+            CFD_HIP(hipMemcpyAsync(C.cj + (size_t)(NG + C.g.nj) * P, C.t + (size_t)(NG + c->comm.nranks - 1) * P,
                                    P * sizeof(double), hipMemcpyDeviceToDevice, st));
         } else if (l + 1 < la) {
-            CFD_TRY(halo_exchange(c, C.g, 2, C.ci, C.cj, C.D));
+            CFD_TRY(halo_exchange(c, C.g, NG, C.ci, C.cj, C.D));
         }
     }
     c->p_built = true;
@@ -1818,7 +1820,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (level_fusable(c, L.g, cg)) {
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
-            CFD_TRY(halo_exchange(c, L.g, 2, const_cast<double *>(rhs[l])));
+            CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
             if (l == 0) {
                 c->probe_begin(1);
                 if (KS == 3)
@@ -1847,7 +1849,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             hipLaunchKernelGGL(k_mg_restrict, dim3(Tc.blocks), block2d(), 0, st, op, rhs[l], cur[l], cg, Tc, fi, fj, cb);
             CFD_HIP(hipGetLastError());
         }
-        if (to_agg) CFD_TRY(all_gather_rows(c, cb + 2 * (size_t)cg.pitch, C.b + 2 * (size_t)cg.pitch, (size_t)cg.nj * cg.pitch));
+        if (to_agg) CFD_TRY(all_gather_rows(c, cb + NG * (size_t)cg.pitch, C.b + NG * (size_t)cg.pitch, (size_t)cg.nj * cg.pitch));
     }
     {
         const Level &L = c->levels[nl - 1];
@@ -1879,11 +1881,11 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         // (whose neighbouring rows are the halo), or the exchanged slab plane
         const double *e = cur[l + 1];
         if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
-        else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, 1, cur[l + 1]));
+        else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, level_fusable(c, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
         if (level_fusable(c, L.g, cg)) {
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
-            CFD_TRY(halo_exchange(c, L.g, 2, cur[l]));
+            CFD_TRY(halo_exchange(c, L.g, KS, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
                 if (KS == 3)
@@ -2012,7 +2014,7 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         double pa = 0.0, pb = 0.0, pc, po_b = 0.0, po_c;
         double d_b = 1.0, cw_b = 0.0, ce_b = 0.0, cs_b = 0.0, cn_b = 0.0;
-        size_t cell_b = 2 * P + colo;
+        size_t cell_b = NG * P + colo;
         // software pipeline: row j + 1 is loaded while row j is processed
         struct RowIn {
             double z, po, d, cw, ce, cs, cn, xv;
@@ -2022,15 +2024,15 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df
         auto fetch = [&](int j, RowIn &R) {
             const int mr = mem_row(j, g, op.per_j);
             R.valid = cvalid && mr >= 0;
-            const size_t cc = (size_t)(mr >= 0 ? mr : 2) * P + colo;
+            const size_t cc = (size_t)(mr >= 0 ? mr : NG) * P + colo;
             R.cell = cc;
             R.po = first ? 0.0 : pold[cc];
             R.z = z[cc];
             R.xv = (first || xzero) ? 0.0 : x[cc];      // xzero: x = 0 was never stored (second iteration)
             R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
-            R.cn = op.cj[cc + (mr < g.nj + 3 ? P : 0)];
+            R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
             // rows j0-1 .. j1 only: the outermost halo row is never touched here
-            R.d = df.on ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, (mr >= 0 ? mr : 2) - 2, df, op) : op.D[cc];
+            R.d = df.on ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, (mr >= 0 ? mr : NG) - NG, df, op) : op.D[cc];
         };
         RowIn nxt;
         fetch(j0 - 1, nxt);

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
         const bool ilo = iraw == 0, ihi = iraw == g.ni;
         const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
         auto fetch = [&](int j, FluxRow &R) {
-            const size_t c = (size_t)(j + 2) * P + colo;
+            const size_t c = (size_t)(j + NG) * P + colo;
             R.u = f.u[c]; R.v = f.v[c]; R.p = f.p[c];
             R.ap = rc ? f.ap[c] : 1.0;
             R.wri = m.wri[c]; R.nix = m.nix[c]; R.niy = m.niy[c]; R.si = m.si[c];
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 if (jo >= j0 && out) {
                     const double fw = fw_p, fe = fe_p, fs = fs_p, fn = fs_c;
                     const double vol = prv.vol;
-                    const size_t c = (size_t)(jo + 2) * P + colo;
+                    const size_t c = (size_t)(jo + NG) * P + colo;
                     // upwind (solver.py:649-669)
                     double advu, advv;
                     {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 const double vol = prv.vol;
                 const double div = (fe_p - fw_p + fs_c - fs_p) / vol;
                 if (MODE == 0) acc += div * div;
-                else { const double bv = vol * (-div); bout[(size_t)(jo + 2) * P + colo] = bv; acc += bv; }   // sum b (nullspace form)
+                else { const double bv = vol * (-div); bout[(size_t)(jo + NG) * P + colo] = bv; acc += bv; }   // sum b (nullspace form)
             }
             fw_p = fw_c; fs_p = fs_c;
             prv = cur;

@@ -190,7 +190,7 @@ class Device:
         omega / omega2: the older two-value form."""
         if omegas is None:
             if omega is None:
-                omegas = (1.0, 0.55, 0.9) if nu_pre == 3 and self.nranks == 1 else (1.0, 0.6)
+                omegas = (1.0, 0.55, 0.9) if nu_pre == 3 else (1.0, 0.6)
             else:
                 omegas = (omega,) if not omega2 else (omega, omega2)
         om = np.ascontiguousarray(omegas, dtype=np.float64)

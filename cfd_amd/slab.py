@@ -85,17 +85,18 @@ class SlabComm:
             return plan
         dist = self.dist
         n = depth * pitch
+        ng = _lib.GHOST_ROWS
         up, dn = self.rank + 1, self.rank - 1
         sends, recvs = [], []   # (tensor, peer)
         for p in plane_ptrs:
             def row(r, p=p):
                 return self.view(p + 8 * r * pitch, n)
             if up < self.nranks:
-                sends.append((row(2 + nj_local - depth), up))
-                recvs.append((row(2 + nj_local), up))
+                sends.append((row(ng + nj_local - depth), up))
+                recvs.append((row(ng + nj_local), up))
             if dn >= 0:
-                sends.append((row(2), dn))
-                recvs.append((row(2 - depth), dn))
+                sends.append((row(ng), dn))
+                recvs.append((row(ng - depth), dn))
         ops = None
         if not self.staged:
             ops = [dist.P2POp(dist.isend, t, self._peer(peer), self.group) for t, peer in sends]
@@ -107,7 +108,7 @@ class SlabComm:
 
     def halo(self, plane_ptrs, pitch, nj_local, depth):
         """Rows [nj-d, nj) -> rows [-d, 0) of rank+1 ; rows [0, d) -> rows [nj, nj+d) of rank-1.
-        Plane row r holds j = r - 2 (two ghost rows below the interior)."""
+        Plane row r holds j = r - GHOST_ROWS."""
         dist = self.dist
         sends, recvs, ops = self._halo_plan(plane_ptrs, pitch, nj_local, depth)
         if not sends:

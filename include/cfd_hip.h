@@ -48,6 +48,11 @@ enum { CFD_F_U = 0, CFD_F_V = 1, CFD_F_P = 2, CFD_F_K = 3, CFD_F_OMEGA = 4, CFD_
 /* turbulence closures (turbulence.py:19-62) */
 enum { CFD_TURB_KOMEGA = 0, CFD_TURB_SST = 1 };
 
+/* Ghost rows below and above the interior rows of every device plane (plane row r holds j = r - CFD_GHOST_ROWS):
+ * the halo callback of a j-slab host addresses rows with it (cfd_set_comm); depth <= CFD_GHOST_ROWS.        */
+#define CFD_GHOST_ROWS 4
+int cfd_ghost_rows(void);
+
 /* array kinds (host shapes) */
 enum { CFD_KIND_CELL_GHOSTED = 0, CFD_KIND_CELL = 1, CFD_KIND_FACE_I = 2, CFD_KIND_FACE_J = 3 };
 

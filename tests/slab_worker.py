@@ -88,6 +88,44 @@ def mesh_from_rect_check(out_dir, rank, world):
         dist.destroy_process_group()
 
 
+def kernel_check(name, out_dir, rank, world):
+    """One fused V-cycle on a random right-hand side and one SIMPLE iteration with the solver statistics:
+    what the cut handling of the fused kernels (three sweeps / four Chebyshev iterations per pass, halo rows from
+    the neighbour) must reproduce exactly, not just up to the solver tolerance."""
+    import torch.distributed as dist
+    from cfd_amd import _lib as L
+    from cfd_amd import solver as S
+    from cfd_amd.bc import BoundaryGeometry
+    from cfd_amd.slab import gather_slabs, slab_device, slab_of
+    work = out_dir / f"rank{rank}"
+    cfg = build_case(name, work)
+    mesh = S.load_mesh(cfg["mesh"])
+    ctl = S.StepControl(cfg)
+    fields = S.initialize_fields(mesh, cfg["initial"])
+    ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
+    fields.setdefault("nu_t", np.zeros((ni + 2, nj + 2)))
+    r = np.random.default_rng(3).standard_normal((ni, nj))
+    dev = slab_device(ni, nj, 0, min_slab_rows=int(os.environ.get("SLAB_MIN_ROWS", "16")))
+    dev.upload_mesh(mesh)
+    S.configure_device(dev, cfg, BoundaryGeometry.from_nodes(mesh["node"]), cfg["physics"]["nu"], ctl.turb_on)
+    dev.upload_fields(fields)
+    dev.apply_flow_bc()
+    dt = dev.compute_dt(0.5, 0.5, 0.0, 1.0e-3)[0]
+    dev.momentum_diagonal(dt)
+    z = dev.vcycle(slab_of(r, dev.j_offset, dev.nj, L.KIND_CELL))
+    if world > 1:
+        z = gather_slabs(z, L.KIND_CELL, dev.nj, world)
+    res = dev.simple_iter(dt, 0.7, 0.7, 0.3)
+    st = dev.stats()
+    dev.close()
+    if rank == 0:
+        np.savez(out_dir / "result.npz", z=z, res=np.array(res), mom_iters=st["mom_iters"], p_iters=st["p_iters"],
+                 cheb=int(st["mom_solver"] == "chebyshev"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     name, out_dir, backend = sys.argv[1], Path(sys.argv[2]), sys.argv[3]
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,6 +138,8 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     if name == "mesh_from_rect":
         return mesh_from_rect_check(out_dir, rank, world)
+    if name.startswith("kernels:"):
+        return kernel_check(name.split(":", 1)[1], out_dir, rank, world)
     from cfd_amd import solver as hip_solver
     cfg = build_case(name, work)
     cfg["solver"]["device"] = 0

@@ -81,3 +81,17 @@ def test_slab_mesh_from_rect(world, tmp_path):
     res = _run("mesh_from_rect", world, tmp_path / f"m{world}")
     assert res["worst"].shape == (world,)
     assert np.all(res["worst"] <= 1e-12), res["worst"]
+
+
+@pytest.mark.parametrize("case,world", [("channel_lam_64x128", 2), ("channel_komega_48x64", 2), ("channel_komega_48x64", 4)])
+def test_fused_kernels_across_cuts(case, world, tmp_path):
+    """The fused kernels read up to four halo rows of the neighbour slab: one V(3,3) cycle on a random
+    right-hand side agrees with the single-rank cycle to rounding, and one SIMPLE iteration takes the same
+    Chebyshev / MG-PCG iteration counts (a wrong halo would only show up there: the solves still converge)."""
+    one = _run("kernels:" + case, 1, tmp_path / "w1")
+    many = _run("kernels:" + case, world, tmp_path / f"w{world}")
+    scale = np.abs(one["z"]).max()
+    assert np.abs(one["z"] - many["z"]).max() <= 1e-12 * scale
+    assert int(one["mom_iters"]) == int(many["mom_iters"]) and int(one["p_iters"]) == int(many["p_iters"])
+    assert int(one["cheb"]) == int(many["cheb"]) == 1
+    assert np.allclose(one["res"], many["res"], rtol=1e-9, atol=1e-15)

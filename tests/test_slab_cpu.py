@@ -83,7 +83,8 @@ def _comm_worker(rank, world, port, out_q):
         from cfd_amd import _lib as L
         from cfd_amd.slab import SlabComm, gather_slabs, partition, slab_of
         pitch, njl, nplanes = 32, 6, 3
-        rows = njl + 4
+        ng = L.GHOST_ROWS
+        rows = njl + 2 * ng
         ws = torch.zeros((nplanes * rows * pitch + 64) * 8, dtype=torch.uint8)
         comm = SlabComm(ws, rank, world)
         f = comm.f64
@@ -93,16 +94,17 @@ def _comm_worker(rank, world, port, out_q):
             for q in range(nplanes):
                 v = f[q * rows * pitch:(q + 1) * rows * pitch].view(rows, pitch)
                 v.fill_(-1.0)
-                for r in range(2, 2 + njl):          # interior row j = r - 2 -> code rank, plane, global row
-                    v[r] = 1000.0 * rank + 100.0 * q + (rank * njl + r - 2) + 0.001 * torch.arange(pitch, dtype=torch.float64)
-        for depth in (1, 2):
+                for r in range(ng, ng + njl):        # interior row j = r - ng -> code rank, plane, global row
+                    v[r] = 1000.0 * rank + 100.0 * q + (rank * njl + r - ng) + 0.001 * torch.arange(pitch, dtype=torch.float64)
+        depths = tuple(range(1, ng + 1))
+        for depth in depths:
             fill()
             comm.halo(planes, pitch, njl, depth)
             for q in range(nplanes):
                 v = f[q * rows * pitch:(q + 1) * rows * pitch].view(rows, pitch)
                 col = 0.001 * torch.arange(pitch, dtype=torch.float64)
                 for d in range(1, depth + 1):
-                    lo, hi = v[2 - d], v[2 + njl + d - 1]
+                    lo, hi = v[ng - d], v[ng + njl + d - 1]
                     if rank > 0:
                         assert torch.equal(lo, 1000.0 * (rank - 1) + 100.0 * q + (rank * njl - d) + col), (depth, d)
                     else:
@@ -124,15 +126,15 @@ def _comm_worker(rank, world, port, out_q):
         assert f[s_off:s_off + 2].tolist() == [5.0 - (world - 1), 2.0]
         # all-gather of slab rows into a replicated plane (plane 2 used as destination)
         fill()
-        src = planes[0] + 8 * 2 * pitch
-        dst = planes[2] + 8 * 2 * pitch
+        src = planes[0] + 8 * ng * pitch
+        dst = planes[2] + 8 * ng * pitch
         n_each = 2 * pitch                              # 2 rows per rank -> 2 * world rows <= njl
         comm.all_gather(src, dst, n_each)
         g = f[2 * rows * pitch:3 * rows * pitch].view(rows, pitch)
         for r in range(world):
             for k in range(2):
-                assert g[2 + 2 * r + k, 0].item() == 1000.0 * r + (r * njl + k)
-        assert (comm.n_halo, comm.n_reduce, comm.n_gather) == (2, 2, 1)
+                assert g[ng + 2 * r + k, 0].item() == 1000.0 * r + (r * njl + k)
+        assert (comm.n_halo, comm.n_reduce, comm.n_gather) == (len(depths), 2, 1)
         # out-of-workspace pointers are refused, and a failing callback reports instead of raising through C
         assert comm._reduce_cb(None, comm.base - 8, 1, 0) == 1 and isinstance(comm.error, ValueError)
         L.LAST_CALLBACK_ERROR = None
