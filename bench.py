@@ -10,13 +10,13 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
 
 The JSON line also carries
   roofline     : the kernel with the largest share of device time, k_chebk<2,4> (momentum solve: four fused
-                 Jacobi-Chebyshev iterations of u and v per launch; 15.7 % in profiles/r1j_*), timed live with
+                 Jacobi-Chebyshev iterations of u and v per launch; 15.4 % in profiles/r1k_*), timed live with
                  HIP-event pairs around every launch inside the timed steps; achieved = 104 B/cell * Ni*Nj /
                  avg duration (x_k, x_k-1, b of both right-hand sides, D, c_i, c_j read; two iterates of each
                  written).  --probe 0 / 7 / 1 / 2 / 9 select the PCG direction step k_cg_pq (14.6 %), the
                  multigrid up / down kernels, the momentum RHS kernel or the single-RHS Chebyshev kernel.
                  traffic = HBM bytes per launch from the committed PMC passes of this command
-                 (profiles/r1j_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
+                 (profiles/r1k_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
                  were measured on.
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
                  factor-once LU pressure) timed on this host, bounded sample.
@@ -38,8 +38,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
-# 8192^2 (profiles/r1j_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.55, 9: 70.53, 7: 41.65, 1: 33.86, 2: 117.63}
+# 8192^2 (profiles/r1k_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.55, 9: 70.53, 7: 41.65, 1: 33.87, 2: 117.50}
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1):
@@ -219,7 +219,7 @@ def main():
         kernel_names = {0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq)",
                         1: "MG pre-smoother, finest level: 2 fused Jacobi sweeps + residual + restrict (k_mg_down<true>)",
                         2: "momentum RHS + continuity sum, marching Rhie-Chow flux kernel (k_flux_march<2>)", 3: "batched momentum operator (k_bi_apply<2>)",
-                        8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>; k_cheb2<2> on j-slab runs)",
+                        8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>)",
                         9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
                         7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
         bytes_per_cell = {0: 64, 1: 34, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104, 9: 64}[args.probe]
