@@ -44,7 +44,9 @@ PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.55, 9: 70.53, 7: 41.65, 1: 3
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1):
     """One n x n slab per GPU of an n x (n * world) channel of height `world` (same cells, same cell
-    size on every rank: weak scaling); world = 1 is the single-GPU workload of SURVEY.md 8(d)."""
+    size on every rank: weak scaling); world = 1 is the single-GPU workload of SURVEY.md 8(d).
+    --strong calls this with world = 1 under an initialised process group: the n x n channel itself is
+    split into one n x (n / N) slab per GPU."""
     from cfd_amd import _lib as L
     from cfd_amd.bc import BoundaryGeometry
     from cfd_amd.mesh import rect_node_axes
@@ -125,6 +127,9 @@ def main():
     ap.add_argument("--mg-omega", type=float, default=None, help="smoother damping of the even sweeps")
     ap.add_argument("--mg-omega2", type=float, default=None, help="smoother damping of the odd sweeps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the --size x --size channel is split over the N GPUs (default: weak, one "
+                         "--size x --size slab per GPU)")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use GPU 0 (with --backend gloo), numbers are not a measurement")
     args = ap.parse_args()
@@ -154,7 +159,9 @@ def main():
     from cfd_amd.solver import advance_one_step
 
     n = args.size
-    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, world)
+    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if args.strong else world)
+    cells_total = n * n if args.strong else world * n * n
+    cells_gpu = cells_total // world   # cells one launch on this GPU sweeps
     if args.mg_sweeps is not None or args.mg_omegas is not None:
         nu_s = args.mg_sweeps or 3
         dev.set_multigrid(nu_pre=nu_s, nu_post=nu_s,
@@ -212,7 +219,7 @@ def main():
         copy_gbs = 10 * 2 * 8.0 * n * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
     ms_per_step = 1000.0 * elapsed / args.steps
-    value = world * n * n / (elapsed / args.steps)
+    value = cells_total / (elapsed / args.steps)
 
     out = None
     if rank == 0:
@@ -223,10 +230,10 @@ def main():
                         9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
                         7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
         bytes_per_cell = {0: 64, 1: 34, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104, 9: 64}[args.probe]
-        achieved = bytes_per_cell * n * n / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
+        achieved = bytes_per_cell * cells_gpu / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": (PMC_TRAFFIC_BYTES_PER_CELL_8192[args.probe] * n * n
+                    "traffic": (PMC_TRAFFIC_BYTES_PER_CELL_8192[args.probe] * cells_gpu
                                 if n == 8192 and world == 1 and not args.turbulent and args.probe in PMC_TRAFFIC_BYTES_PER_CELL_8192
                                 else None),
                     "traffic_unit": "bytes per launch (PMC, committed profile)",
@@ -236,15 +243,17 @@ def main():
         out = {
             "metric": "cell-updates/s per outer step", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.shared_gpu else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
             "config": {"workload": f"synthetic {n}x{n} periodic channel with pressure-gradient forcing "
                                    f"({'k-omega' if args.turbulent else 'laminar'}), SIMPLE max_iter={args.max_iter}, "
                                    f"continuity_tol=0, cfl=cfl_diff=0.5, dt_max={cfg['time']['dt_max']:.3g}, rtol={args.tol:g}",
-                       "cells_per_gpu": n * n,
+                       "cells_per_gpu": cells_gpu,
                        "parallelism": "1 GPU" if world == 1 else
-                       f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel (height {world}), halo exchange + "
-                       f"all-reduce over RCCL, coarse multigrid levels replicated",
+                       (f"{world} j-slabs of {n}x{n // world} cells of the {n}x{n} channel (strong scaling)"
+                        if args.strong else
+                        f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel (height {world})")
+                       + ", halo exchange + all-reduce over RCCL, coarse multigrid levels replicated",
                        "collectives_per_step": None if dev.comm is None else dict(zip(
                            ("halo_exchanges", "all_reduces", "all_gathers"),
                            [(a - b) / args.steps for a, b in zip((dev.comm.n_halo, dev.comm.n_reduce, dev.comm.n_gather), comm0)])),
@@ -265,8 +274,8 @@ def main():
         out["pressure_solve"] = {
             "ms_per_solve": 1e3 * press_s, "iterations": mean_p_it,
             "algorithmic_bytes_per_cell_per_iteration": pcg_bytes_per_cell_iter,
-            "achieved_GBps": pcg_bytes_per_cell_iter * mean_p_it * n * n / press_s / 1e9 if press_s > 0 else None,
-            "frac_of_hbm_peak": pcg_bytes_per_cell_iter * mean_p_it * n * n / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
+            "achieved_GBps": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 if press_s > 0 else None,
+            "frac_of_hbm_peak": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
             "note": "includes the pressure right-hand side kernel and the host residual checks of the solve"}
         out["phase_ms_per_step"] = {k: 1e3 * v / extra_steps for k, v in phases.items()}
         out["device_copy_GBps"] = copy_gbs
