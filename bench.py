@@ -42,7 +42,7 @@ SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read 
 PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.55, 9: 70.53, 7: 41.65, 1: 33.87, 2: 117.50}
 
 
-def setup_device(n, turbulent, max_iter, tol, device, world=1):
+def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None):
     """One n x n slab per GPU of an n x (n * world) channel of height `world` (same cells, same cell
     size on every rank: weak scaling); world = 1 is the single-GPU workload of SURVEY.md 8(d).
     --strong calls this with world = 1 under an initialised process group: the n x n channel itself is
@@ -56,7 +56,7 @@ def setup_device(n, turbulent, max_iter, tol, device, world=1):
 
     cfg, mp = channel_forced_config(n, turbulent, max_iter, tol, nj=n * world, length_j=float(world))
     x, y = rect_node_axes(**mp)
-    dev = slab_device(n, n * world, device)
+    dev = slab_device(n, n * world, device, transport=transport)
     dev.mesh_from_rect(x, y)
     ctl = StepControl(cfg)
     configure_device(dev, cfg, BoundaryGeometry.from_rect_axes(x, y), cfg["physics"]["nu"], ctl.turb_on)
@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--mg-omega", type=float, default=None, help="smoother damping of the even sweeps")
     ap.add_argument("--mg-omega2", type=float, default=None, help="smoother damping of the odd sweeps")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--transport", default=None, choices=("rccl", "torch"),
+                    help="slab collectives: rccl = enqueued by the library itself (default under the nccl backend), "
+                         "torch = torch.distributed callbacks (default under gloo, host-staged)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the --size x --size channel is split over the N GPUs (default: weak, one "
                          "--size x --size slab per GPU)")
@@ -146,6 +149,10 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     if world > 1:
+        if args.shared_gpu:
+            # functional rehearsal of the RCCL transports on a one-GPU box (loopback sockets, not a measurement)
+            from cfd_amd.slab import rehearsal_env
+            rehearsal_env(rank)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -159,7 +166,7 @@ def main():
     from cfd_amd.solver import advance_one_step
 
     n = args.size
-    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if args.strong else world)
+    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if args.strong else world, args.transport)
     cells_total = n * n if args.strong else world * n * n
     cells_gpu = cells_total // world   # cells one launch on this GPU sweeps
     if args.mg_sweeps is not None or args.mg_omegas is not None:
@@ -176,7 +183,7 @@ def main():
         step += 1
     dev.synchronize()
     dev.probe(args.probe)
-    comm0 = (dev.comm.n_halo, dev.comm.n_reduce, dev.comm.n_gather) if dev.comm is not None else (0, 0, 0)
+    comm0 = dev.comm_counts()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -253,10 +260,12 @@ def main():
                        (f"{world} j-slabs of {n}x{n // world} cells of the {n}x{n} channel (strong scaling)"
                         if args.strong else
                         f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel (height {world})")
-                       + ", halo exchange + all-reduce over RCCL, coarse multigrid levels replicated",
+                       + ", halo rows + all-reduce + coarse-level all-gather "
+                       + ("enqueued by the library over RCCL" if dev.transport == "rccl" else
+                          f"through torch.distributed ({args.backend}) callbacks") + ", coarse multigrid levels replicated",
                        "collectives_per_step": None if dev.comm is None else dict(zip(
                            ("halo_exchanges", "all_reduces", "all_gathers"),
-                           [(a - b) / args.steps for a, b in zip((dev.comm.n_halo, dev.comm.n_reduce, dev.comm.n_gather), comm0)])),
+                           [(a - b) / args.steps for a, b in zip(dev.comm_counts(), comm0)])),
                        "inner_iterations": args.max_iter,
                        "mean_momentum_iters": float(it[:, 0].mean()), "mean_pressure_iters": float(it[:, 1].mean()),
                        "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,

@@ -18,6 +18,7 @@ F_U, F_V, F_P, F_K, F_OMEGA, F_NUT, F_PCORR, F_AP, F_AI, F_AJ, F_BU, F_BV = rang
 F_SST_S, F_SST_F1, F_SST_F2, F_SST_DK, F_SST_DW, F_SST_DWALL = range(12, 18)
 TURB_KOMEGA, TURB_SST = 0, 1
 KIND_GHOSTED, KIND_CELL, KIND_FACE_I, KIND_FACE_J = range(4)
+RCCL_ID_BYTES = 128     # CFD_RCCL_ID_BYTES of include/cfd_hip.h
 GHOST_ROWS = 4          # CFD_GHOST_ROWS of include/cfd_hip.h (checked against cfd_ghost_rows() when the library loads)
 SIDE_IMIN, SIDE_IMAX, SIDE_JMIN, SIDE_JMAX = range(4)
 SIDES = {"i_min": 0, "i_max": 1, "j_min": 2, "j_max": 3}
@@ -123,6 +124,9 @@ SIGNATURES.update({
     "cfd_create_slab": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "cfd_set_comm": (C.c_int, [_vp, HALO_FN, ALLREDUCE_FN, ALLGATHER_FN, _vp]),
     "cfd_exchange_field": (C.c_int, [_vp, C.c_int]),
+    "cfd_rccl_unique_id": (C.c_int, [_vp, C.c_size_t]),
+    "cfd_set_comm_rccl": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "cfd_comm_counts": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "cfd_level_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 })
 

@@ -321,6 +321,7 @@ int cfd_destroy(cfd_ctx *ctx) {
     Ctx *c = &ctx->c;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    rccl_release(c);
     for (hipEvent_t e : c->probe_e0) hipEventDestroy(e);
     for (hipEvent_t e : c->probe_e1) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -337,7 +338,24 @@ int cfd_destroy(cfd_ctx *ctx) {
 int cfd_set_comm(cfd_ctx *ctx, cfd_halo_fn halo, cfd_allreduce_fn allreduce, cfd_allgather_fn allgather, void *user) {
     CTX_MUT(ctx);
     if (c->comm.nranks > 1 && (!halo || !allreduce || !allgather)) { set_error("cfd_set_comm: null callback"); return CFD_E_ARG; }
+    if (c->stream) CFD_HIP(hipStreamSynchronize(c->stream));
+    rccl_release(c);
     c->comm.halo = halo; c->comm.allreduce = allreduce; c->comm.allgather = allgather; c->comm.user = user;
+    return CFD_OK;
+}
+
+int cfd_rccl_unique_id(void *id, size_t bytes) { return rccl_unique_id(id, bytes); }
+
+int cfd_set_comm_rccl(cfd_ctx *ctx, const void *id, size_t bytes) {
+    CTX_MUT(ctx);
+    if (c->stream) CFD_HIP(hipStreamSynchronize(c->stream));
+    return rccl_attach(c, id, bytes);
+}
+
+int cfd_comm_counts(cfd_ctx *ctx, long long counts[3], int *native) {
+    CTX(ctx);
+    if (counts) { counts[0] = c->comm.n_halo; counts[1] = c->comm.n_reduce; counts[2] = c->comm.n_gather; }
+    if (native) *native = c->comm.rccl != nullptr;
     return CFD_OK;
 }
 

@@ -128,6 +128,8 @@ struct Comm {
     cfd_allreduce_fn allreduce = nullptr;
     cfd_allgather_fn allgather = nullptr;
     void *user = nullptr;
+    void *rccl = nullptr;         // ncclComm_t of the native transport (comm.hip); takes precedence over the callbacks
+    long long n_halo = 0, n_reduce = 0, n_gather = 0;
 };
 
 // ------------------------------------------------------------------ context
@@ -308,6 +310,9 @@ int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b = nullpt
                   double *e = nullptr);
 int all_reduce(Ctx *c, double *dev, int n, int op);    // op: 0 sum, 1 min
 int all_gather_rows(Ctx *c, const double *src, double *dst, size_t elems_each);
+int rccl_unique_id(void *id, size_t bytes);
+int rccl_attach(Ctx *c, const void *id, size_t bytes);
+void rccl_release(Ctx *c);
 inline double global_cells(const Ctx *c) {
     return (double)c->g.ni * (double)(c->comm.nranks > 1 ? c->comm.nj_global : c->g.nj);
 }

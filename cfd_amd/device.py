@@ -28,6 +28,20 @@ class Device:
     # context holds rows [j_offset, j_offset + nj) of a mesh with nj_global rows.
     rank, nranks, j_offset = 0, 1, 0
     comm = None
+    transport = None
+
+    def comm_counts(self):
+        """(halo exchanges, all-reduces, all-gathers) this context has issued so far (0, 0, 0 on one rank)."""
+        cnt = (C.c_longlong * 3)()
+        native = C.c_int(0)
+        check(self.lib.cfd_comm_counts(self._h, cnt, C.byref(native)))
+        return tuple(int(v) for v in cnt)
+
+    def comm_native(self):
+        """True when the library's own RCCL communicator carries the slab collectives."""
+        native = C.c_int(0)
+        check(self.lib.cfd_comm_counts(self._h, None, C.byref(native)))
+        return bool(native.value)
 
     @property
     def nj_global(self):

@@ -1,13 +1,17 @@
 """j-slab decomposition of the outer step over several GPUs.
 
 One process per GPU; rank r owns rows [r * nj_local, (r + 1) * nj_local) of the global mesh.
-The library (csrc/comm.hip) asks for three collectives through C callbacks, which this module
-implements with torch.distributed:
+The library (csrc/comm.hip) needs three collectives (halo rows, all-reduce, all-gather).  Transports:
 
-  * backend "nccl" (= RCCL over xGMI on MI355X): zero-copy views of the device workspace, all
-    operations enqueued on the context's HIP stream;
-  * backend "gloo": the same views staged through host memory.  This is how the N > 1 path is
-    tested where only one GPU (or none: the exchange logic alone, on CPU tensors) is available.
+  * "rccl" (default when the process group's backend is nccl): the library's own RCCL communicator --
+    the collectives are enqueued from C++ on the context's stream, torch.distributed only carries the
+    128-byte unique id to the ranks once;
+  * "torch": C callbacks into this module, implemented with torch.distributed -- backend "nccl" on
+    zero-copy views of the device workspace, backend "gloo" with the same views staged through host
+    memory (how the N > 1 logic is tested without RCCL, and on CPU tensors without any GPU).
+
+On a one-GPU box several ranks can rehearse the RCCL transports on the same device when every rank poses
+as a host of its own (`rehearsal_env`): RCCL then talks over its loopback socket transport.
 
 The reference has no counterpart: its run_case (solver.py:1367-1451) is single-process.
 """
@@ -183,10 +187,36 @@ class SlabComm:
 DEFAULT_MIN_SLAB_ROWS = 512
 
 
-def slab_device(ni, nj_global, device=0, group=None, min_slab_rows=None):
+def rehearsal_env(rank):
+    """Several ranks on ONE GPU (functional rehearsal only): RCCL refuses two ranks of one host on one device,
+    so each rank gets a host id of its own and RCCL uses its socket transport over loopback.  Call before the
+    first RCCL communicator is created (torch's or the library's)."""
+    import os
+    os.environ["NCCL_HOSTID"] = f"rehearsal-host-{int(rank)}"
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+
+def attach_rccl(dev, group=None):
+    """Give the slab context the library's own RCCL communicator (collective over `group`)."""
+    import torch.distributed as dist
+    ident = [None]
+    if dev.rank == 0:
+        buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+        check(dev.lib.cfd_rccl_unique_id(buf, _lib.RCCL_ID_BYTES))
+        ident[0] = buf.raw
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(ident, src=src, group=group)
+    buf = C.create_string_buffer(ident[0], _lib.RCCL_ID_BYTES)
+    check(dev.lib.cfd_set_comm_rccl(dev._h, buf, _lib.RCCL_ID_BYTES))
+
+
+def slab_device(ni, nj_global, device=0, group=None, min_slab_rows=None, transport=None):
     """Device context of this rank's slab; torch.distributed must be initialised when world > 1.
     min_slab_rows: multigrid levels stay slab-distributed while a slab keeps at least this many rows
-    (3 halo exchanges per level and V-cycle); coarser levels are replicated on every rank."""
+    (3 halo exchanges per level and V-cycle); coarser levels are replicated on every rank.
+    transport: "rccl" (library-native RCCL), "torch" (torch.distributed callbacks); default: environment
+    variable CFD_SLAB_TRANSPORT, else "rccl" under an nccl process group and "torch" otherwise."""
     min_slab_rows = max(16, int(DEFAULT_MIN_SLAB_ROWS if min_slab_rows is None else min_slab_rows))
     import torch
     import torch.distributed as dist
@@ -216,9 +246,18 @@ def slab_device(ni, nj_global, device=0, group=None, min_slab_rows=None):
                               int(rank), int(world), min_slab_rows))
     check(lib.cfd_set_stream(dev._h, C.c_void_p(stream.cuda_stream)))
     comm = SlabComm(ws, rank, world, group=group, stream=stream)
-    comm.install(lib, dev._h)
     dev._ws, dev._stream, dev.comm = ws, stream, comm     # keep alive as long as the context
     dev.j_offset, dev.nj_global, dev.rank, dev.nranks = j_off, int(nj_global), rank, world
+    import os
+    transport = transport or os.environ.get("CFD_SLAB_TRANSPORT") or \
+        ("rccl" if dist.get_backend(group) == "nccl" else "torch")
+    if transport == "rccl":
+        attach_rccl(dev, group)
+    elif transport == "torch":
+        comm.install(lib, dev._h)
+    else:
+        raise ValueError(f"unknown slab transport {transport!r} (rccl | torch)")
+    dev.transport = transport
     return dev
 
 

@@ -443,7 +443,8 @@ def run_case(config):
     if _distributed_world() > 1:
         from .slab import slab_device
         dev = slab_device(count_i, count_j, default_device_ordinal(solver_cfg),
-                          min_slab_rows=solver_cfg.get("slab", {}).get("min_rows"))
+                          min_slab_rows=solver_cfg.get("slab", {}).get("min_rows"),
+                          transport=solver_cfg.get("slab", {}).get("transport"))
     else:
         dev = Device(count_i, count_j, default_device_ordinal(solver_cfg))
     root = dev.rank == 0

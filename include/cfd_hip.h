@@ -111,7 +111,7 @@ int cfd_destroy(cfd_ctx *ctx);
  * Communication goes through three callbacks that the host implements on the context's
  * stream (torch.distributed over RCCL in cfd_amd/slab.py); each returns 0 on success.   */
 /* exchange `depth` rows at each cut of `nplanes` planes of pitch `pitch` (doubles) and
- * nj_local interior rows: plane row r holds j = r - 2.  My rows [nj_local-depth, nj_local) go to
+ * nj_local interior rows: plane row r holds j = r - CFD_GHOST_ROWS.  My rows [nj_local-depth, nj_local) go to
  * rows [-depth, 0) of rank+1, my rows [0, depth) to rows [nj_local, nj_local+depth) of rank-1.  */
 typedef int (*cfd_halo_fn)(void *user, int nplanes, double *const *planes, int pitch, int nj_local, int depth);
 /* in-place all-reduce of n device doubles; op 0 = sum, 1 = min                                  */
@@ -124,6 +124,17 @@ size_t cfd_workspace_bytes_slab(int ni, int nj_local, int nranks, int min_slab_r
 int cfd_create_slab(cfd_ctx **out, int ni, int nj_local, int device, void *workspace, size_t workspace_bytes,
                     int rank, int nranks, int min_slab_rows);
 int cfd_set_comm(cfd_ctx *ctx, cfd_halo_fn halo, cfd_allreduce_fn allreduce, cfd_allgather_fn allgather, void *user);
+/* Native transport: the library itself enqueues the three collectives on the context's stream with RCCL
+ * (grouped ncclSend / ncclRecv of the halo rows to the two neighbours, ncclAllReduce, ncclAllGather), no host
+ * code between the kernels.  No counterpart in the reference (run_case, solver.py:1367-1451, is one process).
+ * Rank 0 calls cfd_rccl_unique_id and hands the CFD_RCCL_ID_BYTES bytes to every rank by any host channel;
+ * then all ranks call cfd_set_comm_rccl (collective, blocking).  The transport set last is the one in use.
+ * RCCL is loaded at run time (librccl.so.1), preferring a copy the process already holds.                    */
+#define CFD_RCCL_ID_BYTES 128
+int cfd_rccl_unique_id(void *id, size_t bytes);
+int cfd_set_comm_rccl(cfd_ctx *ctx, const void *id, size_t bytes);
+/* collectives issued so far by this context: halo exchanges, all-reduces, all-gathers; native = 1 with RCCL */
+int cfd_comm_counts(cfd_ctx *ctx, long long counts[3], int *native);
 /* refresh the cut ghost rows of a field plane (after cfd_upload_field on every rank)            */
 int cfd_exchange_field(cfd_ctx *ctx, int field_id);
 /* number of multigrid levels and index of the first replicated one (0 on a single rank)         */

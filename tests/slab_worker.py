@@ -1,10 +1,14 @@
 """One rank of a j-slab run (started by tests/test_gpu_slab.py, once per rank).
 
     RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment
-    python tests/slab_worker.py <case> <out_dir> <backend>
+    python tests/slab_worker.py <case> <out_dir> <mode>
 
-Every rank shares GPU 0 (the test box has one GPU), so the transport is gloo with host
-staging; on a multi-GPU node the same code runs with backend nccl and one GPU per rank.
+Every rank shares GPU 0 (the test box has one GPU).  mode selects process-group backend and slab transport:
+    gloo        gloo group, torch.distributed callbacks staged through the host
+    rccl        gloo group for the host side, the library's native RCCL transport for the slabs
+    nccl        nccl group, native RCCL transport (what a multi-GPU node runs by default)
+    nccl-torch  nccl group, torch.distributed callbacks on device views
+The RCCL modes rehearse on one device with one fake host id per rank (cfd_amd.slab.rehearsal_env).
 Rank 0 writes <out_dir>/result.npz.
 """
 import os
@@ -117,17 +121,20 @@ def kernel_check(name, out_dir, rank, world):
         z = gather_slabs(z, L.KIND_CELL, dev.nj, world)
     res = dev.simple_iter(dt, 0.7, 0.7, 0.3)
     st = dev.stats()
+    native, counts = dev.comm_native(), dev.comm_counts()
     dev.close()
     if rank == 0:
         np.savez(out_dir / "result.npz", z=z, res=np.array(res), mom_iters=st["mom_iters"], p_iters=st["p_iters"],
-                 cheb=int(st["mom_solver"] == "chebyshev"))
+                 cheb=int(st["mom_solver"] == "chebyshev"), native=int(native), counts=np.array(counts))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
 def main():
-    name, out_dir, backend = sys.argv[1], Path(sys.argv[2]), sys.argv[3]
+    name, out_dir, mode = sys.argv[1], Path(sys.argv[2]), sys.argv[3]
+    backend, transport = {"gloo": ("gloo", "torch"), "rccl": ("gloo", "rccl"), "nccl": ("nccl", None),
+                          "nccl-torch": ("nccl", "torch")}[mode]
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     work = out_dir / f"rank{rank}"
     work.mkdir(parents=True, exist_ok=True)
@@ -135,7 +142,15 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(0)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if mode != "gloo":
+            from cfd_amd.slab import rehearsal_env
+            rehearsal_env(rank)
+        if transport:
+            os.environ["CFD_SLAB_TRANSPORT"] = transport
+        else:
+            os.environ.pop("CFD_SLAB_TRANSPORT", None)
+        kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     if name == "mesh_from_rect":
         return mesh_from_rect_check(out_dir, rank, world)
     if name.startswith("kernels:"):

@@ -1,7 +1,9 @@
 """j-slab decomposition on the GPU: N ranks, each with its own libcfd_hip
 context holding one slab, must reproduce the single-rank run.  The box has one GPU, so the
-ranks share it and exchange through gloo with host staging; the halo / all-reduce /
-all-gather logic and every kernel's cut handling are the ones the RCCL path uses."""
+ranks share it: most cases exchange through gloo with host staging (the halo / all-reduce /
+all-gather logic and every kernel's cut handling are the ones the RCCL path uses), and the RCCL
+transports themselves -- the library's native one and the torch.distributed nccl callbacks -- are
+rehearsed on the shared device with one fake host id per rank (RCCL's loopback socket transport)."""
 import os
 import socket
 import subprocess
@@ -23,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(case, world, out_dir, min_rows=16):
+def _run(case, world, out_dir, min_rows=16, mode="gloo"):
     out_dir.mkdir(parents=True, exist_ok=True)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
                HSA_ENABLE_IPC_MODE_LEGACY="0", SLAB_MIN_ROWS=str(min_rows))
@@ -31,7 +33,7 @@ def _run(case, world, out_dir, min_rows=16):
     for rank in range(world):
         e = dict(env, RANK=str(rank), LOCAL_RANK="0")
         log = open(out_dir / f"rank{rank}.log", "w")
-        procs.append((subprocess.Popen([sys.executable, "-u", str(ROOT / "tests" / "slab_worker.py"), case, str(out_dir), "gloo"],
+        procs.append((subprocess.Popen([sys.executable, "-u", str(ROOT / "tests" / "slab_worker.py"), case, str(out_dir), mode],
                                        env=e, stdout=log, stderr=subprocess.STDOUT, cwd=str(ROOT)), log))
     failed = []
     for rank, (p, log) in enumerate(procs):
@@ -72,6 +74,29 @@ def test_slab_run_matches_single_rank(case, world, min_rows, tmp_path):
     assert la.shape == lb.shape
     assert np.array_equal(la[:, 0], lb[:, 0]) and np.array_equal(la[:, 2], lb[:, 2])     # steps, inner iterations
     assert np.all(np.abs(la[:, 3] - lb[:, 3]) <= 1e-6 * np.abs(la[:, 3]) + 1e-13)        # continuity history
+
+
+@pytest.mark.parametrize("mode,world", [("rccl", 2), ("rccl", 4), ("nccl", 2), ("nccl-torch", 2)])
+def test_rccl_transports(mode, world, tmp_path):
+    """The same k-omega slab run over the RCCL transports (native: ncclSend / ncclRecv groups, ncclAllReduce,
+    ncclAllGather enqueued by the library; nccl-torch: the callbacks on device views): fields and logs of the
+    single-rank run, and the fused kernels' iteration counts."""
+    case = "channel_komega_48x64"
+    one = _run(case, 1, tmp_path / "w1")
+    many = _run(case, world, tmp_path / f"w{world}", 16, mode)
+    assert int(one["step"]) == int(many["step"])
+    unorm = max(1.0, np.linalg.norm(one["field_u"].ravel()))
+    for key in [k for k in one.files if k.startswith("field_") and k != "field_p_corr"]:
+        a, b = mask_corners(one[key]), mask_corners(many[key])
+        err, den = np.linalg.norm((a - b).ravel()), np.linalg.norm(a.ravel())
+        assert err <= 1e-10 * den + 1e-12 * unorm, (key, err, den)
+    assert np.array_equal(one["log"][:, 2], many["log"][:, 2])
+    k1 = _run("kernels:" + case, 1, tmp_path / "k1")
+    kn = _run("kernels:" + case, world, tmp_path / f"k{world}", 16, mode)
+    assert np.abs(k1["z"] - kn["z"]).max() <= 1e-12 * np.abs(k1["z"]).max()
+    assert int(k1["mom_iters"]) == int(kn["mom_iters"]) and int(k1["p_iters"]) == int(kn["p_iters"])
+    assert int(kn["native"]) == (mode != "nccl-torch") and int(k1["native"]) == 0
+    assert np.all(kn["counts"] > 0) and not np.any(k1["counts"])
 
 
 @pytest.mark.parametrize("world", [1, 3])
