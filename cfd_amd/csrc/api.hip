@@ -888,6 +888,7 @@ int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, dou
 static int sst_step(Ctx *c, double dt) {
     if (!c->cc_set) { set_error("SST needs the cell centres (cfd_upload_cell_centers)"); return CFD_E_STATE; }
     CFD_TRY(launch_turb_bc(c));
+    CFD_TRY(halo_exchange(c, c->g, 1, c->k, c->omega));      // wall BCs also overwrite interior cells
     if (!c->sst_dw_set) {                       // _d_wall is computed once (turbulence.py:345-346)
         CFD_TRY(launch_wall_distance(c));
         c->sst_dw_set = true;
@@ -896,6 +897,7 @@ static int sst_step(Ctx *c, double dt) {
     CFD_TRY(launch_eddy_viscosity(c));          // limiter with the _S of the PREVIOUS update (none in the first)
     CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
     c->dt_ap = dt;
+    CFD_TRY(halo_exchange(c, c->g, 1, c->ap));               // Rhie-Chow reads a_P across the cut
     double *sk = c->kry[13], *sw = c->kry[14];
     CFD_TRY(launch_sst_sources(c));             // _S, _F1, _F2, _D_k, _D_omega + adv + source of k, omega
     c->sst_cached = true;
@@ -919,6 +921,7 @@ static int sst_step(Ctx *c, double dt) {
     CFD_TRY(launch_clip(c, c->k, c->k_clip));
     CFD_TRY(launch_clip(c, c->omega, c->omega_clip));
     CFD_TRY(launch_turb_bc(c));
+    CFD_TRY(halo_exchange(c, c->g, 1, c->k, c->omega));
     return launch_sst_f2_full(c);
 }
 
@@ -926,7 +929,6 @@ int cfd_set_turbulence_model(cfd_ctx *ctx, int model) {
     CTX_MUT(ctx);
     if (model != CFD_TURB_KOMEGA && model != CFD_TURB_SST) { set_error("unknown turbulence model %d", model); return CFD_E_ARG; }
     if (model == CFD_TURB_SST) {
-        if (c->comm.nranks > 1) { set_error("the SST closure is single-rank only"); return CFD_E_STATE; }
         if (!c->sst_mem) {
             const size_t pb = c->g.plane_elems() * sizeof(double);
             CFD_HIP(hipMalloc((void **)&c->sst_mem, 11 * pb));
@@ -948,6 +950,7 @@ int cfd_upload_cell_centers(cfd_ctx *ctx, const double *cell_center) {
     if (!c->sst_mem) { set_error("cfd_upload_cell_centers: select the SST closure first"); return CFD_E_STATE; }
     double *pl[2] = {c->m_xc, c->m_yc};
     CFD_TRY(to_device_comp(c, cell_center, 2, pl, CFD_KIND_CELL));
+    CFD_TRY(halo_exchange(c, c->g, 1, c->m_xc, c->m_yc));    // j-slabs: central differences across the cuts
     c->cc_set = true;
     c->sst_dw_set = false;
     return CFD_OK;

@@ -1064,6 +1064,7 @@ __global__ void k_ghost_extend(Geo g, Planes6 pl) {
     else if (t < 2 * (g.ni + 2)) { ig = t - (g.ni + 2); jg = g.nj + 1; }
     else if (t < 2 * (g.ni + 2) + g.nj) { ig = 0; jg = t - 2 * (g.ni + 2) + 1; }
     else { ig = g.ni + 1; jg = t - 2 * (g.ni + 2) - g.nj + 1; }
+    if ((jg == 0 && g.cutlo) || (jg == g.nj + 1 && g.cuthi)) return;     // a cut: the neighbour's row (halo exchange)
     const int is = min(max(ig, 1), g.ni), js = min(max(jg, 1), g.nj);
     for (int q = 0; q < pl.n; ++q) pl.p[q][g.at(ig, jg)] = pl.p[q][g.at(is, js)];
 }
@@ -1073,6 +1074,10 @@ static int launch_ghost_extend(Ctx *c, std::initializer_list<double *> planes) {
     const int per = 2 * (c->g.ni + 2) + 2 * c->g.nj;
     hipLaunchKernelGGL(k_ghost_extend, dim3((per + 255) / 256), dim3(256), 0, c->stream, c->g, pl);
     CFD_HIP(hipGetLastError());
+    // j-slabs: the i-edge ghosts of my rows are set, now the cut rows (ghost columns included) from the neighbours
+    for (int q = 0; q < pl.n; q += 4)
+        CFD_TRY(halo_exchange(c, c->g, 1, pl.p[q], q + 1 < pl.n ? pl.p[q + 1] : nullptr, q + 2 < pl.n ? pl.p[q + 2] : nullptr,
+                              q + 3 < pl.n ? pl.p[q + 3] : nullptr));
     return CFD_OK;
 }
 
@@ -1129,8 +1134,8 @@ __global__ void k_sst_sources(Geo g, MeshDev m, FluxIn f, const double *om, cons
     else if (i == 0) dx = 2.0 * (xc[c + 1] - xc[c]);
     else dx = 2.0 * (xc[c] - xc[c - 1]);
     if (fabs(dx) < 1.0e-15) dx = 1.0;
-    if (j > 0 && j < g.nj - 1) dy = yc[c + P] - yc[c - P];
-    else if (j == 0) dy = 2.0 * (yc[c + P] - yc[c]);
+    if (!g.blo(j) && !g.bhi(j)) dy = yc[c + P] - yc[c - P];      // at a cut: the neighbour's cell-centre row
+    else if (g.blo(j)) dy = 2.0 * (yc[c + P] - yc[c]);
     else dy = 2.0 * (yc[c] - yc[c - P]);
     if (fabs(dy) < 1.0e-15) dy = 1.0;
     const double kx = (kk[c + 1] - kk[c - 1]) / dx, ky = (kk[c + P] - kk[c - P]) / dy;

@@ -175,7 +175,10 @@ class Device:
             return
         if mesh is None or bc_cfg is None:
             raise ValueError("the SST closure needs the mesh (cell_center, node) and the boundary config")
-        cc = _f64(mesh["cell_center"])
+        cc = np.asarray(mesh["cell_center"])
+        if self.nranks > 1 and cc.shape == (self.ni, self.nj_global, 2):
+            cc = cc[:, self.j_offset:self.j_offset + self.nj]          # this slab's rows of the whole mesh
+        cc = _f64(cc)
         if cc.shape != (self.ni, self.nj, 2):
             raise ValueError(f"cell_center is {cc.shape}, context is {(self.ni, self.nj, 2)}")
         check(self.lib.cfd_upload_cell_centers(self._h, dptr(cc)))

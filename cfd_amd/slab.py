@@ -38,6 +38,13 @@ def partition(nj_global, nranks, rank):
     return rank * nj_local, nj_local
 
 
+class _ForeignPlane:
+    """n device doubles at a raw address, for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
 class SlabComm:
     """The three collectives on views of one flat workspace tensor.
 
@@ -68,6 +75,9 @@ class SlabComm:
     def view(self, ptr, n):
         off = int(ptr) - self.base
         if off < 0 or off % 8 or off + 8 * int(n) > self.ws.numel():
+            if self.ws.is_cuda and int(ptr) % 8 == 0:
+                # a device plane the library allocated itself (the SST caches): zero-copy view of foreign memory
+                return self.torch.as_tensor(_ForeignPlane(int(ptr), int(n)), device=self.ws.device)
             raise ValueError("pointer outside the workspace")
         return self.f64[off // 8: off // 8 + int(n)]
 

@@ -186,7 +186,7 @@ int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, 
                    double turb_tol, int turb_maxiter, int freeze_pressure);
 /* multigrid shape: pre/post Jacobi sweeps, damping, coarsest-level sweeps; fused = 1 uses
  * the temporally blocked marching kernels (all sweeps of a pass in one kernel) when
- * nu_pre = nu_post = 2, or 3 on single-rank contexts                                        */
+ * nu_pre = nu_post = 2 or 3                                                                 */
 int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused);
 /* Damping of the odd smoothing sweeps (the even ones use `omega` of cfd_set_multigrid); the sweeps of one
  * pass commute, so the preconditioner stays symmetric.  Defaults omega = 1.0, omega2 = 0.6: the smoothing
@@ -196,8 +196,8 @@ int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int c
  * smoother choice, solver.py:821-833.)                                                                  */
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
 /* General form: n = 1..4 damping factors in (0, 2), mean <= 1, used cyclically by the sweeps of a pass.
- * Defaults: single-rank contexts V(3,3) with (1.0, 0.55, 0.9) (three sweeps fused per pass: 5 MG-PCG
- * iterations per solve at 8192^2), j-slab contexts V(2,2) with (1.0, 0.6) (a cut carries two halo rows).  */
+ * Default: V(3,3) with (1.0, 0.55, 0.9) (three sweeps fused per pass: 5 MG-PCG iterations per solve at
+ * 8192^2); j-slab contexts run the same kernels (a cut carries CFD_GHOST_ROWS halo rows).              */
 int cfd_set_smoother_omegas(cfd_ctx *ctx, int n, const double *omegas);
 /* Systems without any Dirichlet pressure (the reference pins one cell, solver.py:1033-1044):
  *   on = 1 (default): when the operator is symmetric the singular system is solved with every row kept
@@ -266,11 +266,13 @@ int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, dou
 int cfd_turbulence_step(cfd_ctx *ctx, double dt);
 /* Turbulence closure: CFD_TURB_KOMEGA (default; turbulence.py:19-34, 388-394, 427-444) or CFD_TURB_SST
  * (Menter SST, turbulence.py:41-208, 343-386, 447-566).  SST allocates its eleven extra planes (six
- * caches, cell centres, the omega transport operator) once, outside the caller's workspace; single-rank
- * contexts only.  It needs cfd_upload_cell_centers and cfd_set_wall_faces before the first step.      */
+ * caches, cell centres, the omega transport operator) once, outside the caller's workspace (a host that
+ * implements the cfd_set_comm callbacks sees those pointers in its halo callback on j-slab runs).  It needs
+ * cfd_upload_cell_centers and cfd_set_wall_faces before the first step.                                */
 int cfd_set_turbulence_model(cfd_ctx *ctx, int model);
 /* mesh["cell_center"] (Ni, Nj, 2) (mesh.py:375-394): read by the SST wall distance and the
- * finite-difference gradients of k and omega (turbulence.py:96-136, 179-208)                          */
+ * finite-difference gradients of k and omega (turbulence.py:96-136, 179-208).  j-slabs: the slab's rows;
+ * collective (the rows next to a cut are exchanged); cfd_set_wall_faces takes the wall faces of the WHOLE mesh */
 int cfd_upload_cell_centers(cfd_ctx *ctx, const double *cell_center);
 /* Face centres (n, 2) of every boundary face of type "wall", all segments concatenated
  * (turbulence._wall_face_centers, turbulence.py:69-93); n = 0: no wall (distance 1.0)                 */

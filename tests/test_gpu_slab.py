@@ -58,6 +58,8 @@ def _run(case, world, out_dir, min_rows=16, mode="gloo"):
     ("channel_komega_48x64", 2, 16), ("channel_komega_48x64", 4, 16), ("channel_lam_64x128", 2, 16),
     ("channel_lam_64x128", 2, 512),      # production threshold: only the finest level is slab-distributed
     ("inlet_outlet_40x32", 2, 16), ("couette_piso_24x32", 2, 16), ("half_cylinder_komega_24x32", 2, 16),
+    # Menter SST on slabs: caches, wall distance and cell-centre differences across the cuts
+    ("channel_sst_48x64", 2, 16), ("channel_sst_48x64", 4, 16), ("half_cylinder_sst_24x32", 2, 16),
 ])
 def test_slab_run_matches_single_rank(case, world, min_rows, tmp_path):
     """min_rows = 16 keeps the multigrid levels slab-distributed as deep as the mesh allows."""
@@ -74,6 +76,21 @@ def test_slab_run_matches_single_rank(case, world, min_rows, tmp_path):
     assert la.shape == lb.shape
     assert np.array_equal(la[:, 0], lb[:, 0]) and np.array_equal(la[:, 2], lb[:, 2])     # steps, inner iterations
     assert np.all(np.abs(la[:, 3] - lb[:, 3]) <= 1e-6 * np.abs(la[:, 3]) + 1e-13)        # continuity history
+
+
+@pytest.mark.parametrize("mode", ["rccl", "nccl-torch"])
+def test_sst_slabs_over_rccl(mode, tmp_path):
+    """The SST planes live outside the workspace: both RCCL transports must reach them."""
+    case = "channel_sst_48x64"
+    one = _run(case, 1, tmp_path / "w1")
+    many = _run(case, 2, tmp_path / "w2", 16, mode)
+    unorm = max(1.0, np.linalg.norm(one["field_u"].ravel()))
+    keys = [k for k in one.files if k.startswith("field_") and k != "field_p_corr"]
+    assert "field__F1" in keys and "field__d_wall" in keys
+    for key in keys:
+        a, b = mask_corners(one[key]), mask_corners(many[key])
+        err, den = np.linalg.norm((a - b).ravel()), np.linalg.norm(a.ravel())
+        assert err <= 1e-10 * den + 1e-12 * unorm, (key, err, den)
 
 
 @pytest.mark.parametrize("mode,world", [("rccl", 2), ("rccl", 4), ("nccl", 2), ("nccl-torch", 2)])
