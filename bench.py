@@ -212,6 +212,18 @@ def main():
         step += 1
     phases = dev.phase_times(reset=True)
     dev.enable_phase_timing(False)
+    # the other kernels BASELINE.json's target names (momentum RHS / Rhie-Chow, MG smoother, PCG step): one more
+    # step each with the event-pair probe on that kernel
+    others = {}
+    for pid in (2, 1, 7, 0, 8):
+        if pid == args.probe:
+            continue
+        dev.probe(pid)
+        advance_one_step(dev, ctl, step)
+        step += 1
+        dev.synchronize()
+        others[pid] = dev.probe_read()
+        dev.probe(-1)
     copy_gbs = None
     if rank == 0:
         a = torch.empty(n * n, dtype=torch.float64, device="cuda")
@@ -231,12 +243,13 @@ def main():
     out = None
     if rank == 0:
         kernel_names = {0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq)",
-                        1: "MG pre-smoother, finest level: 2 fused Jacobi sweeps + residual + restrict (k_mg_down<true>)",
+                        1: "MG pre-smoother, finest level: 3 fused Jacobi sweeps + residual + restrict (k_mg_down_k<true,3>)",
                         2: "momentum RHS + continuity sum, marching Rhie-Chow flux kernel (k_flux_march<2>)", 3: "batched momentum operator (k_bi_apply<2>)",
                         8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>)",
                         9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
-                        7: "MG post-smoother, finest level: prolong + 2 fused Jacobi sweeps + (r,z) (k_mg_up<true>)"}
-        bytes_per_cell = {0: 64, 1: 34, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104, 9: 64}[args.probe]
+                        7: "MG post-smoother, finest level: prolong + 3 fused Jacobi sweeps + (r,z) (k_mg_up_k<true,3>)"}
+        bpc_table = {0: 64, 1: 34, 2: 120, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104, 9: 64}
+        bytes_per_cell = bpc_table[args.probe]
         achieved = bytes_per_cell * cells_gpu / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
@@ -271,6 +284,11 @@ def main():
                        "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,
                        "last_continuity_l2": info["cont"], "last_dt": info["dt"]},
             "roofline": roofline,
+            "roofline_other_kernels": [
+                {"kernel": kernel_names[pid], "bytes_per_cell": bpc_table[pid], "avg_us": us, "launches_timed": cnt,
+                 "achieved": bpc_table[pid] * cells_gpu / (us * 1e-6) / 1e9 if cnt else None, "unit": "GB/s",
+                 "frac": bpc_table[pid] * cells_gpu / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if cnt else None}
+                for pid, (cnt, us) in others.items()],
         }
         # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes of one
         # MG-PCG iteration over all levels: finest level 64 (k_cg_pq) + 24 (k_cg_r) + 34 (k_mg_down)

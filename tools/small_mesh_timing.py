@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Step time of the bench workload on small meshes (launch / host-sync bound regime): python tools/small_mesh_timing.py"""
+import json
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import bench  # noqa: E402
+from cfd_amd.solver import advance_one_step  # noqa: E402
+
+for n, turb in ((32, False), (64, False), (128, False), (256, False), (512, False), (1024, False), (64, True), (256, True)):
+    dev, ctl, cfg = bench.setup_device(n, turb, 2, 1e-8, 0)
+    step = 0
+    for _ in range(5):
+        advance_one_step(dev, ctl, step)
+        step += 1
+    dev.synchronize()
+    t0 = time.perf_counter()
+    k = 20
+    for _ in range(k):
+        advance_one_step(dev, ctl, step)
+        step += 1
+    dev.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / k
+    st = dev.stats()
+    print(json.dumps({"n": n, "turbulent": turb, "ms_per_step": round(ms, 3), "cells_per_s": round(n * n / ms * 1e3),
+                      "mom_iters": st["mom_iters"], "p_iters": st["p_iters"], "k_iters": st["k_iters"]}), flush=True)
+    dev.close()
