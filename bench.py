@@ -184,6 +184,7 @@ def main():
     dev.synchronize()
     dev.probe(args.probe)
     comm0 = dev.comm_counts()
+    phase0 = dev.comm_counts_by_phase()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -200,6 +201,7 @@ def main():
         elapsed = float(t.item())
     n_probe, probe_us = dev.probe_read()
     dev.probe(-1)
+    comm1, phase1 = dev.comm_counts(), dev.comm_counts_by_phase()
     # ---- outside the timed region: per-phase device times of two more steps (event pairs with a host
     # sync per phase, which is why they are not collected inside the timed steps) and a plain
     # device-to-device copy of one plane as the streaming reference figure of this GPU
@@ -278,7 +280,9 @@ def main():
                           f"through torch.distributed ({args.backend}) callbacks") + ", coarse multigrid levels replicated",
                        "collectives_per_step": None if dev.comm is None else dict(zip(
                            ("halo_exchanges", "all_reduces", "all_gathers"),
-                           [(a - b) / args.steps for a, b in zip(dev.comm_counts(), comm0)])),
+                           [(a - b) / args.steps for a, b in zip(comm1, comm0)])),
+                       "collectives_per_step_by_phase": None if dev.comm is None else {
+                           ph: [(a - b) / args.steps for a, b in zip(phase1[ph], phase0[ph])] for ph in phase1},
                        "inner_iterations": args.max_iter,
                        "mean_momentum_iters": float(it[:, 0].mean()), "mean_pressure_iters": float(it[:, 1].mean()),
                        "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,

@@ -352,6 +352,14 @@ int cfd_set_comm_rccl(cfd_ctx *ctx, const void *id, size_t bytes) {
     return rccl_attach(c, id, bytes);
 }
 
+int cfd_comm_counts_by_phase(cfd_ctx *ctx, long long counts[27]) {
+    CTX(ctx);
+    if (!counts) return CFD_E_ARG;
+    for (int p = 0; p < 9; ++p)
+        for (int k = 0; k < 3; ++k) counts[3 * p + k] = c->comm.by_phase[p][k];
+    return CFD_OK;
+}
+
 int cfd_comm_counts(cfd_ctx *ctx, long long counts[3], int *native) {
     CTX(ctx);
     if (counts) { counts[0] = c->comm.n_halo; counts[1] = c->comm.n_reduce; counts[2] = c->comm.n_gather; }
@@ -709,8 +717,13 @@ int cfd_set_turb_bc(cfd_ctx *ctx, int n_ops, const cfd_turb_op *ops, int n_value
 struct Phase {
     Ctx *c;
     int id;
-    Phase(Ctx *c_, int id_) : c(c_), id(id_) { if (c->timing) hipEventRecord(c->ev0, c->stream); }
+    int outer;
+    Phase(Ctx *c_, int id_) : c(c_), id(id_), outer(c_->comm.phase) {
+        c->comm.phase = id;
+        if (c->timing) hipEventRecord(c->ev0, c->stream);
+    }
     ~Phase() {
+        c->comm.phase = outer;
         if (!c->timing) return;
         hipEventRecord(c->ev1, c->stream);
         hipEventSynchronize(c->ev1);

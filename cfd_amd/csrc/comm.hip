@@ -102,22 +102,28 @@ int rccl_attach(Ctx *c, const void *id, size_t bytes) {
 }
 
 // Rows [nj-d, nj) -> rows [-d, 0) of rank+1 ; rows [0, d) -> rows [nj, nj+d) of rank-1 (plane row r holds j = r - NG).
-// Every plane's four messages go into one RCCL group: one launch per exchange.
-int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b, double *d, double *e) {
-    if (c->comm.nranks <= 1 || !(g.cutlo || g.cuthi)) return CFD_OK;
-    if (depth < 1 || depth > NG || depth > g.nj) { set_error("halo depth %d not possible on %d rows", depth, g.nj); return CFD_E_ARG; }
-    double *pl[4] = {a, b, d, e};
-    int n = 0;
-    while (n < 4 && pl[n]) ++n;
-    ++c->comm.n_halo;
+// Every plane's four messages go into one RCCL group: one launch per exchange, whatever the planes' geometries.
+int halo_exchange_multi(Ctx *c, int n, const HaloSpec *specs) {
+    if (c->comm.nranks <= 1 || n <= 0) return CFD_OK;
+    for (int q = 0; q < n; ++q) {
+        const Geo &g = *specs[q].g;
+        if (!(g.cutlo || g.cuthi)) { set_error("halo exchange on a level without cuts"); return CFD_E_ARG; }
+        if (specs[q].depth < 1 || specs[q].depth > NG || specs[q].depth > g.nj || !specs[q].plane) {
+            set_error("halo depth %d not possible on %d rows", specs[q].depth, g.nj);
+            return CFD_E_ARG;
+        }
+    }
     if (c->comm.rccl) {
+        ++c->comm.n_halo; ++c->comm.by_phase[c->comm.phase][0];
         ncclComm_t comm = (ncclComm_t)c->comm.rccl;
-        const size_t P = (size_t)g.pitch, cnt = (size_t)depth * P;
         const int up = c->comm.rank + 1, dn = c->comm.rank - 1;
         CFD_RCCL(g_rccl.GroupStart());
         ncclResult_t r = ncclSuccess;
         for (int q = 0; q < n && r == ncclSuccess; ++q) {
-            double *x = pl[q];
+            const Geo &g = *specs[q].g;
+            const size_t P = (size_t)g.pitch, cnt = (size_t)specs[q].depth * P;
+            const int depth = specs[q].depth;
+            double *x = specs[q].plane;
             if (up < c->comm.nranks) {
                 r = g_rccl.Send(x + (size_t)(NG + g.nj - depth) * P, cnt, ncclDouble, up, comm, c->stream);
                 if (r == ncclSuccess) r = g_rccl.Recv(x + (size_t)(NG + g.nj) * P, cnt, ncclDouble, up, comm, c->stream);
@@ -132,17 +138,34 @@ int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b, double 
         if (re != ncclSuccess) return rccl_fail("ncclGroupEnd (halo rows)", re);
         return CFD_OK;
     }
+    // host callbacks take planes of one geometry and depth per call
     CFD_TRY(need_comm(c, (const void *)c->comm.halo, "halo"));
-    if (c->comm.halo(c->comm.user, n, pl, g.pitch, g.nj, depth) != 0) {
-        set_error("halo exchange callback failed");
-        return CFD_E_STATE;
+    for (int q = 0; q < n;) {
+        double *pl[4];
+        int m = 0;
+        const Geo &g = *specs[q].g;
+        const int depth = specs[q].depth;
+        while (q < n && m < 4 && specs[q].depth == depth && specs[q].g->pitch == g.pitch && specs[q].g->nj == g.nj) pl[m++] = specs[q++].plane;
+        ++c->comm.n_halo; ++c->comm.by_phase[c->comm.phase][0];
+        if (c->comm.halo(c->comm.user, m, pl, g.pitch, g.nj, depth) != 0) {
+            set_error("halo exchange callback failed");
+            return CFD_E_STATE;
+        }
     }
     return CFD_OK;
 }
 
+int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b, double *d, double *e) {
+    if (c->comm.nranks <= 1 || !(g.cutlo || g.cuthi)) return CFD_OK;
+    HaloSpec sp[4] = {{&g, depth, a}, {&g, depth, b}, {&g, depth, d}, {&g, depth, e}};
+    int n = 0;
+    while (n < 4 && sp[n].plane) ++n;
+    return halo_exchange_multi(c, n, sp);
+}
+
 int all_reduce(Ctx *c, double *dev, int n, int op) {
     if (c->comm.nranks <= 1) return CFD_OK;
-    ++c->comm.n_reduce;
+    ++c->comm.n_reduce; ++c->comm.by_phase[c->comm.phase][1];
     if (c->comm.rccl) {
         CFD_RCCL(g_rccl.AllReduce(dev, dev, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMin, (ncclComm_t)c->comm.rccl, c->stream));
         return CFD_OK;
@@ -157,7 +180,7 @@ int all_gather_rows(Ctx *c, const double *src, double *dst, size_t elems_each) {
         CFD_HIP(hipMemcpyAsync(dst, src, elems_each * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         return CFD_OK;
     }
-    ++c->comm.n_gather;
+    ++c->comm.n_gather; ++c->comm.by_phase[c->comm.phase][2];
     if (c->comm.rccl) {
         CFD_RCCL(g_rccl.AllGather(src, dst, elems_each, ncclDouble, (ncclComm_t)c->comm.rccl, c->stream));
         return CFD_OK;

@@ -130,6 +130,8 @@ struct Comm {
     void *user = nullptr;
     void *rccl = nullptr;         // ncclComm_t of the native transport (comm.hip); takes precedence over the callbacks
     long long n_halo = 0, n_reduce = 0, n_gather = 0;
+    int phase = 8;                // phase of the outer step the collectives are booked under (8: outside any phase)
+    long long by_phase[9][3] = {};
 };
 
 // ------------------------------------------------------------------ context
@@ -308,6 +310,13 @@ int launch_metrics_from_rect(Ctx *c, const double *x1, const double *y1);
 // comm.hip -- no-ops on a single rank
 int halo_exchange(Ctx *c, const Geo &g, int depth, double *a, double *b = nullptr, double *d = nullptr,
                   double *e = nullptr);
+// several planes of different levels / depths in one exchange (one RCCL group on the native transport)
+struct HaloSpec {
+    const Geo *g;
+    int depth;
+    double *plane;
+};
+int halo_exchange_multi(Ctx *c, int n, const HaloSpec *specs);
 int all_reduce(Ctx *c, double *dev, int n, int op);    // op: 0 sum, 1 min
 int all_gather_rows(Ctx *c, const double *src, double *dst, size_t elems_each);
 int rccl_unique_id(void *id, size_t bytes);

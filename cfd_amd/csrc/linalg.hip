@@ -1810,6 +1810,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     // its four face planes (the coarsening adds D - sum(faces) = 0), so the coarse levels need not read D either
     DiagFix coarse_df{};
     if (c->p_ns_active && c->recompute_diag) { coarse_df.on = 1; coarse_df.pi = -1; coarse_df.pj = -1; }
+    // j-slabs: the right-hand side of the next level and the pre-smoothed x of this one (which the post-smoothing
+    // pass reads) cross the cuts in ONE exchange right after the kernel that produced both
+    std::vector<char> rhs_sent(nl, 0), x_sent(nl, 0);
     for (int l = 0; l < nl - 1; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
@@ -1820,7 +1823,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (level_fusable(c, L.g, cg)) {
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
-            CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
+            if (!rhs_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
             if (l == 0) {
                 c->probe_begin(1);
                 if (KS == 3)
@@ -1834,6 +1837,16 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om, om2, cur[l], cg, cb);
             }
             CFD_HIP(hipGetLastError());
+            if (l < la && (L.g.cutlo || L.g.cuthi)) {
+                HaloSpec sp[2] = {{&L.g, KS, cur[l]}, {nullptr, 0, nullptr}};
+                int ns = 1;
+                x_sent[l] = 1;
+                if (l + 1 < la && l + 2 < nl && level_fusable(c, C.g, coarse_view(c, l + 2))) {
+                    sp[ns++] = HaloSpec{&C.g, KS, cb};
+                    rhs_sent[l + 1] = 1;
+                }
+                CFD_TRY(halo_exchange_multi(c, ns, sp));
+            }
         } else {
             const Tiling T = tiling(L.g);
             hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
@@ -1885,7 +1898,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (level_fusable(c, L.g, cg)) {
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
-            CFD_TRY(halo_exchange(c, L.g, KS, cur[l]));
+            if (!x_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
                 if (KS == 3)

@@ -37,6 +37,13 @@ class Device:
         check(self.lib.cfd_comm_counts(self._h, cnt, C.byref(native)))
         return tuple(int(v) for v in cnt)
 
+    def comm_counts_by_phase(self):
+        """{phase: (halo exchanges, all-reduces, all-gathers)}; phases as in phase_times plus "other"."""
+        cnt = (C.c_longlong * 27)()
+        check(self.lib.cfd_comm_counts_by_phase(self._h, cnt))
+        names = ("bc", "adv", "mom", "press", "corr", "cont", "turb", "dt", "other")
+        return {n: tuple(int(cnt[3 * p + k]) for k in range(3)) for p, n in enumerate(names)}
+
     def comm_native(self):
         """True when the library's own RCCL communicator carries the slab collectives."""
         native = C.c_int(0)

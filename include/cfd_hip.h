@@ -135,6 +135,9 @@ int cfd_rccl_unique_id(void *id, size_t bytes);
 int cfd_set_comm_rccl(cfd_ctx *ctx, const void *id, size_t bytes);
 /* collectives issued so far by this context: halo exchanges, all-reduces, all-gathers; native = 1 with RCCL */
 int cfd_comm_counts(cfd_ctx *ctx, long long counts[3], int *native);
+/* the same three counts per phase of the outer step, counts[3 * phase + kind]; phases in the order of
+ * cfd_phase_times (bc, adv, mom, press, corr, cont, turb, dt), phase 8 = outside any phase              */
+int cfd_comm_counts_by_phase(cfd_ctx *ctx, long long counts[27]);
 /* refresh the cut ghost rows of a field plane (after cfd_upload_field on every rank)            */
 int cfd_exchange_field(cfd_ctx *ctx, int field_id);
 /* number of multigrid levels and index of the first replicated one (0 on a single rank)         */
