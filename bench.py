@@ -18,6 +18,9 @@ The JSON line also carries
                  traffic = HBM bytes per launch from the committed PMC passes of this command
                  (profiles/r1l_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
                  were measured on.
+  strong_scaling_leg (N > 1): after the timed region the same --size x --size channel is split over the N GPUs and
+                 timed the same way; its value / the 1-GPU value is the strong-scaling speed-up.  The headline stays
+                 the weak-scaling figure (one --size x --size slab per GPU); --strong makes the split the headline.
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
                  factor-once LU pressure) timed on this host, bounded sample.
 """
@@ -133,6 +136,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: the --size x --size channel is split over the N GPUs (default: weak, one "
                          "--size x --size slab per GPU)")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="N > 1: skip the strong-scaling leg that follows the (weak-scaling) timed region")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use GPU 0 (with --backend gloo), numbers are not a measurement")
     args = ap.parse_args()
@@ -226,6 +231,37 @@ def main():
         dev.synchronize()
         others[pid] = dev.probe_read()
         dev.probe(-1)
+    # ---- outside the timed region, N > 1 only: the SAME n x n channel split over the N GPUs (strong scaling, the
+    # figure BASELINE.json's target is worded in), timed like the headline: barrier + synchronize on both sides,
+    # max over ranks.  Reported beside the headline as "strong_scaling_leg"; value(N) / value(1 GPU) is its speed-up.
+    strong_leg = None
+    if world > 1 and not args.strong and not args.no_strong_leg and n % world == 0 and (n // world) % 2 == 0 and n // world >= 4:
+        sdev, sctl, _ = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1, args.transport)
+        sstep = 0
+        for _ in range(args.warmup):
+            advance_one_step(sdev, sctl, sstep)
+            sstep += 1
+        sdev.synchronize()
+        s0 = sdev.comm_counts()
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            advance_one_step(sdev, sctl, sstep)
+            sstep += 1
+        sdev.synchronize()
+        barrier()
+        s_elapsed = time.perf_counter() - ts
+        t = torch.tensor([s_elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s_elapsed = float(t.item())
+        sst = sdev.stats()
+        strong_leg = {"workload": f"the {n}x{n} channel as {world} j-slabs of {n}x{n // world} cells",
+                      "ms_per_step": 1e3 * s_elapsed / args.steps, "value": n * n / (s_elapsed / args.steps),
+                      "unit": "cell-updates/s", "steps": args.steps, "warmup": args.warmup,
+                      "pressure_iters_last_step": sst["p_iters"], "momentum_iters_last_step": sst["mom_iters"],
+                      "collectives_per_step": dict(zip(("halo_exchanges", "all_reduces", "all_gathers"),
+                                                       [(a - b) / args.steps for a, b in zip(sdev.comm_counts(), s0)]))}
+        sdev.close()
     copy_gbs = None
     if rank == 0:
         a = torch.empty(n * n, dtype=torch.float64, device="cuda")
@@ -308,6 +344,7 @@ def main():
             "achieved_GBps": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 if press_s > 0 else None,
             "frac_of_hbm_peak": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
             "note": "includes the pressure right-hand side kernel and the host residual checks of the solve"}
+        out["strong_scaling_leg"] = strong_leg
         out["phase_ms_per_step"] = {k: 1e3 * v / extra_steps for k, v in phases.items()}
         out["device_copy_GBps"] = copy_gbs
         if world == 1 and not args.no_cpu:
