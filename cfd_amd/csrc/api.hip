@@ -579,6 +579,7 @@ int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double
     c->cheb_rho_max = rho_max; c->cheb_max_iters = max_iters;
     if (const char *e = getenv("CFD_CHEB_STAGES")) c->cheb_stages = atoi(e);      // tuning / A-B measurements
     if (const char *e = getenv("CFD_MARCH_FLUX")) c->march_flux = atoi(e);
+    if (const char *e = getenv("CFD_FUSE_NUT")) c->fuse_nut = atoi(e);
     if (const char *e = getenv("CFD_RHS_LOOKAHEAD")) c->rhs_lookahead = atoi(e);
     return CFD_OK;
 }
@@ -765,8 +766,12 @@ static int do_predictor(Ctx *c, double dt, double res[3]) {
         // are rebuilt when dt changes or after a turbulence update -- the reference rebuilds the same
         // numbers every inner iteration (solver.py:1600-1601, 868-876)
         if (!c->ap_cached || c->dt_ap != dt) {
-            CFD_TRY(launch_eddy_viscosity(c));
-            CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+            if (c->turbulent && c->turb_model == CFD_TURB_KOMEGA && c->fuse_nut) {
+                CFD_TRY(launch_komega_coeffs(c, dt, false));
+            } else {
+                CFD_TRY(launch_eddy_viscosity(c));
+                CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+            }
             CFD_TRY(halo_exchange(c, c->g, 1, c->ap));     // Rhie-Chow and d_f read a_P across the cut
             c->dt_ap = dt;
             c->ap_cached = true;
@@ -1006,10 +1011,14 @@ int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
     CFD_TRY(launch_turb_bc(c));
     // wall BCs also overwrite interior cells (turbulence.py:304-311): the neighbours' halo rows follow
     CFD_TRY(halo_exchange(c, c->g, 1, c->k, c->omega));
-    CFD_TRY(launch_eddy_viscosity(c));
-    CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+    if (c->fuse_nut) {
+        CFD_TRY(launch_komega_coeffs(c, dt, true));
+    } else {
+        CFD_TRY(launch_eddy_viscosity(c));
+        CFD_TRY(launch_diffusion_ap(c, dt, 1.0, c->ai, c->aj, c->ap));
+        CFD_TRY(launch_diffusion_ap(c, dt, 0.5, c->ti, c->tj, c->tp));
+    }
     c->dt_ap = dt;
-    CFD_TRY(launch_diffusion_ap(c, dt, 0.5, c->ti, c->tj, c->tp));
     CFD_TRY(halo_exchange(c, c->g, 1, c->ap));
     CFD_TRY(launch_turb_rhs(c, dt));
     const OpDev op{c->ti, c->tj, c->tp, c->g, c->per_i, c->per_j};

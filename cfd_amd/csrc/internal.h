@@ -221,6 +221,7 @@ struct Ctx {
     int cheb_max_iters = 80;     // ... and predicted iteration count below this; else BiCGStab
     int stats_last_solver = 0;   // 1 = the last transport solve was Chebyshev
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
+    int fuse_nut = 1;            // k-omega: eddy viscosity evaluated inside the conductance pass (k_komega_coeffs)
     int march_flux = 1;          // marching form of the Rhie-Chow flux kernels (momentum / pressure RHS, continuity)
     // momentum right-hand sides computed ahead of time by the fused continuity pass of the previous
     // inner iteration (valid while the fields, a_P and dt are the ones it saw)
@@ -279,6 +280,7 @@ inline dim3 grid2d(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4, 1
 
 // stencil.hip
 int launch_eddy_viscosity(Ctx *c);
+int launch_komega_coeffs(Ctx *c, double dt, bool both);   // k-omega: nu_t + conductances in one pass
 int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap,
                         const double *nu_plane = nullptr);
 int launch_wall_distance(Ctx *c);

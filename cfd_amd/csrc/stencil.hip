@@ -201,6 +201,70 @@ int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *
     return CFD_OK;
 }
 
+// k-omega: the eddy-viscosity update fused into the conductance pass.  nu_t = k / omega is evaluated on the fly for
+// the cell and its four neighbours (same expression as k_eddy_viscosity, so the planes are bit-identical), the
+// nu_t plane is written as a by-product -- ghost ring and corners included, by the threads of the adjacent boundary
+// cells -- and both conductance sets come out of one pass: momentum (nu + nu_t -> a_i, a_j, a_P) and, with
+// BOTH, the k / omega transport (nu + 0.5 nu_t -> t_i, t_j, t_P; solver.py:1098-1107).  136 instead of
+// 24 + 88 + 88 B/cell.
+template <bool BOTH>
+__global__ void k_komega_coeffs(Geo g, MeshDev m, const double *k, const double *om, double nu, double inv_dt, double *nut,
+                                double *ai, double *aj, double *ap, double *ti, double *tj, double *tp) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const size_t c = g.cell(i, j);
+    const int P = g.pitch;
+    auto nt = [&](size_t q) { return 1.0 * fmax(k[q], K_FLOOR) / fmax(om[q], OMEGA_FLOOR); };
+    const double nP = nt(c), nW = nt(c - 1), nE = nt(c + 1), nS = nt(c - P), nN = nt(c + P);
+    nut[c] = nP;
+    const bool w = i == 0, e = i == g.ni - 1, so = j == 0, no = j == g.nj - 1;
+    if (w) nut[c - 1] = nW;
+    if (e) nut[c + 1] = nE;
+    if (so) nut[c - P] = nS;
+    if (no) nut[c + P] = nN;
+    if (w && so) nut[c - P - 1] = nt(c - P - 1);
+    if (e && so) nut[c - P + 1] = nt(c - P + 1);
+    if (w && no) nut[c + P - 1] = nt(c + P - 1);
+    if (e && no) nut[c + P + 1] = nt(c + P + 1);
+    const double vdt = m.vol[c] * inv_dt;
+    const double wrw = m.wri[c], wre = m.wri[c + 1], wns = m.wnj[c], wnn = m.wnj[c + P];
+#pragma unroll
+    for (int set = 0; set < (BOTH ? 2 : 1); ++set) {
+        const double coef = set == 0 ? 1.0 : 0.5;
+        const double nuP = nu + coef * nP;
+        double nf = nuP;
+        if (i > 0) nf = (1.0 - wrw) * (nu + coef * nW) + wrw * nuP;
+        const double aw = nf * m.si[c] / m.di[c];
+        nf = nuP;
+        if (i < g.ni - 1) nf = (1.0 - wre) * nuP + wre * (nu + coef * nE);
+        const double ae = nf * m.si[c + 1] / m.di[c + 1];
+        nf = nuP;
+        if (!g.blo(j)) nf = (1.0 - wns) * (nu + coef * nS) + wns * nuP;
+        const double as = nf * m.sj[c] / m.dj[c];
+        nf = nuP;
+        if (!g.bhi(j)) nf = (1.0 - wnn) * nuP + wnn * (nu + coef * nN);
+        const double an = nf * m.sj[c + P] / m.dj[c + P];
+        double *oi = set == 0 ? ai : ti, *oj = set == 0 ? aj : tj, *op = set == 0 ? ap : tp;
+        oi[c] = aw;
+        if (e) oi[c + 1] = ae;
+        oj[c] = as;
+        if (no) oj[c + P] = an;
+        op[c] = vdt + aw + ae + as + an;
+    }
+}
+
+// both = true: the turbulence step (momentum and k / omega transport conductances); false: the predictor
+int launch_komega_coeffs(Ctx *c, double dt, bool both) {
+    if (both)
+        hipLaunchKernelGGL((k_komega_coeffs<true>), grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->k, c->omega,
+                           c->nu, 1.0 / dt, c->nut, c->ai, c->aj, c->ap, c->ti, c->tj, c->tp);
+    else
+        hipLaunchKernelGGL((k_komega_coeffs<false>), grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->k, c->omega,
+                           c->nu, 1.0 / dt, c->nut, c->ai, c->aj, c->ap, c->ti, c->tj, c->tp);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
 // ----------------------------------------------------------------------------------
 // flow boundary conditions (bc.py:259-347).  blockIdx.y = side.  Ghosts depend only on
 // interior values, so one launch covers all four sides; the host resolved overlapping

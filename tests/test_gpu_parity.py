@@ -516,6 +516,34 @@ def test_marching_flux_kernels_match_tile_kernels(name, tmp_path):
         assert np.allclose(log[:, 3], ref_log[:, 3], rtol=1e-5, atol=0.0)     # printed with 7 digits
 
 
+@pytest.mark.parametrize("name", ["half_cylinder_komega", "channel_komega_5x20"])
+def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path, monkeypatch):
+    """k-omega: nu_t evaluated inside the conductance pass (k_komega_coeffs: nu_t plane, a_i/a_j/a_P and the
+    k / omega transport conductances in one launch) gives the bits of k_eddy_viscosity + 2 x k_diffusion_ap."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    if name not in cases.ALL_END_TO_END:
+        pytest.skip(f"no case {name}")
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("CFD_FUSE_NUT", fuse)
+        d = tmp_path / f"fuse{fuse}"
+        builder, fixup = cases.ALL_END_TO_END[name]
+        cfg, mp, kind = builder()
+        gen = hip_mesh.generate_rect_mesh if kind == "rect" else hip_mesh.generate_annulus_mesh
+        cfg["mesh"] = {"generator": gen, "params": mp, "path": d / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": d, "mesh_dir": d / "mesh", "states_dir": d / "states", "post_dir": d / "postproc"}
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        if fixup is not None:
+            fixup(cfg, mesh)
+        fields, step, time = hip_solver.run_case(cfg)
+        out[fuse] = (fields, np.loadtxt(d / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2))
+    assert out["0"][0]["nu_t"].any()
+    for key in out["0"][0]:
+        assert np.array_equal(out["0"][0][key], out["1"][0][key]), key
+    assert np.array_equal(out["0"][1], out["1"][1])
+
+
 def test_committed_reference_sst_run(tmp_path):
     """Tier A for the SST closure: the reference's own committed 5x20 SST run (real pyamg, rtol 1e-8):
     first logged steps of the residual / friction logs and states/sst/fields_000000.npz with its caches."""
