@@ -444,18 +444,6 @@ static inline int tiles_of(const Geo &g, int &tx) {
 }
 static inline int red_blocks(int tiles) { return tiles < 2048 ? tiles : 2048; }
 
-int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]) {
-    int tx;
-    const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
-    hipLaunchKernelGGL(k_dt, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), c->U(), c->V(), c->nut, c->nu, use_cfl,
-                       cfl, use_cfl_diff, cfl_diff, c->partials, tx, tiles);
-    CFD_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials, nb, 2, c->scal);
-    CFD_TRY(all_reduce(c, c->scal, 2, 1));    // global minimum over the slabs
-    CFD_HIP(hipGetLastError());
-    return read_scalars(c, 0, 2, out);
-}
-
 // ----------------------------------------------------------------------------------
 // Marching form of the Rhie-Chow flux kernels (momentum RHS, pressure RHS, continuity).
 // One wavefront owns a strip of 62 columns plus one halo lane on each side and walks down the
@@ -469,6 +457,8 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
 //   MODE 0: continuity sum only            (13 planes read,            104 B/cell)
 //   MODE 1: b = -div F (pressure RHS)      (13 read, 1 written,        112 B/cell)
 //   MODE 2: momentum RHS b_u, b_v + the continuity sum of the same fluxes (13 (+k) read, 2 written)
+//   MODE 3: the two global minima of the adaptive time step (solver.py:547-582) from the plain interpolated
+//           fluxes (no Rhie-Chow term): u, v, 7 metric planes, lmin, nu_t read, 88 B/cell
 // ----------------------------------------------------------------------------------
 constexpr int FXW = 62;
 
@@ -492,6 +482,7 @@ struct FluxRow {
     double wri, nix, niy, si;      // west i-face of the cell
     double wnj, njx, njy, sj;      // south j-face of the cell
     double vol, k;
+    double lmin, nut;              // MODE 3 only
 };
 
 struct MomArgs {
@@ -499,6 +490,10 @@ struct MomArgs {
     double inv_dt, force_u, force_v;
     int per_i, per_j;
     double *bu, *bv;
+    // MODE 3 (time step)
+    const double *nut;
+    double nu, cfl, cfl_diff;
+    int use_cfl, use_diff;
 };
 
 template <int MODE, bool KG>
@@ -507,8 +502,8 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
-    const int rc = f.rc;
-    double acc = 0.0;
+    const int rc = MODE == 3 ? 0 : f.rc;
+    double acc = MODE == 3 ? INFINITY : 0.0, acc2 = INFINITY;
     for (int item = blockIdx.x * 4 + wave; item < fm.nstrips * fm.nsegs; item += nw) {
         const int strip = item % fm.nstrips, seg = item / fm.nstrips;
         const int iraw = strip * FXW - 1 + lane;          // -1 .. ni : ghost columns included
@@ -519,12 +514,20 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
         const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
         auto fetch = [&](int j, FluxRow &R) {
             const size_t c = (size_t)(j + NG) * P + colo;
-            R.u = f.u[c]; R.v = f.v[c]; R.p = f.p[c];
-            R.ap = rc ? f.ap[c] : 1.0;
-            R.wri = m.wri[c]; R.nix = m.nix[c]; R.niy = m.niy[c]; R.si = m.si[c];
-            R.wnj = m.wnj[c]; R.njx = m.njx[c]; R.njy = m.njy[c]; R.sj = m.sj[c];
+            R.u = f.u[c]; R.v = f.v[c];
+            R.wri = m.wri[c]; R.nix = m.nix[c]; R.niy = m.niy[c];
+            R.wnj = m.wnj[c]; R.njx = m.njx[c]; R.njy = m.njy[c];
             R.vol = m.vol[c];
-            R.k = KG ? (2.0 / 3.0) * ma.kgrad[c] : 0.0;
+            if (MODE == 3) {
+                R.p = 0.0; R.ap = 1.0; R.si = 0.0; R.sj = 0.0; R.k = 0.0;
+                R.lmin = ma.use_diff ? m.lmin[c] : 1.0;
+                R.nut = ma.use_diff ? ma.nut[c] : 0.0;
+            } else {
+                R.p = f.p[c];
+                R.ap = rc ? f.ap[c] : 1.0;
+                R.si = m.si[c]; R.sj = m.sj[c];
+                R.k = KG ? (2.0 / 3.0) * ma.kgrad[c] : 0.0;
+            }
         };
         FluxRow nxt, cur{}, prv{};
         double u2 = 0.0, v2 = 0.0, p2 = 0.0, k2 = 0.0;      // row j-2 (MODE 2)
@@ -633,6 +636,20 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                     acc += div * div;
                 }
                 u2 = prv.u; v2 = prv.v; p2 = prv.p; k2 = prv.k;
+            } else if (MODE == 3) {
+                if (jo >= j0 && out) {
+                    if (ma.use_cfl) {
+                        const double tot = fabs(fw_p) + fabs(fe_p) + fabs(fs_p) + fabs(fs_c);
+                        const double safe = tot > TINY ? tot : TINY;
+                        acc = fmin(acc, ma.cfl * prv.vol / safe);
+                    }
+                    if (ma.use_diff) {
+                        const double ne = ma.nu + prv.nut;
+                        const double ns = ne > 0.0 ? ne : TINY;
+                        const double l = prv.lmin;
+                        acc2 = fmin(acc2, ma.cfl_diff * (l * l) / ns);
+                    }
+                }
             } else if (jo >= j0 && out) {
                 const double vol = prv.vol;
                 const double div = (fe_p - fw_p + fs_c - fs_p) / vol;
@@ -643,13 +660,47 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
             prv = cur;
         }
     }
-    {
+    if (MODE == 3) {
+        __shared__ double sa[4], sb[4];
+        const double wa = wave_min(acc), wb = wave_min(acc2);
+        if (lane == 0) { sa[wave] = wa; sb[wave] = wb; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            partials[blockIdx.x] = fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3]));
+            partials[MAX_PARTIALS + blockIdx.x] = fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3]));
+        }
+    } else {
         __shared__ double sm[4];
         const double w = wave_sum(acc);
         if (lane == 0) sm[wave] = w;
         __syncthreads();
         if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
     }
+}
+
+int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]) {
+    int nb;
+    if (c->march_flux) {
+        // marching form: every row of u, v and of the metric planes is read once (88 instead of ~117 B/cell)
+        const FluxMarch fm = flux_march_geo(c->g);
+        nb = fm.blocks;
+        FluxIn f{c->U(), c->V(), nullptr, nullptr, nullptr, 0};
+        MomArgs ma{};
+        ma.nut = c->nut; ma.nu = c->nu; ma.cfl = cfl; ma.cfl_diff = cfl_diff; ma.use_cfl = use_cfl; ma.use_diff = use_cfl_diff;
+        hipLaunchKernelGGL((k_flux_march<3, false>), dim3(nb), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma, (double *)nullptr,
+                           c->partials);
+    } else {
+        int tx;
+        const int tiles = tiles_of(c->g, tx);
+        nb = red_blocks(tiles);
+        hipLaunchKernelGGL(k_dt, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), c->U(), c->V(), c->nut, c->nu, use_cfl,
+                           cfl, use_cfl_diff, cfl_diff, c->partials, tx, tiles);
+    }
+    CFD_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials, nb, 2, c->scal);
+    CFD_TRY(all_reduce(c, c->scal, 2, 1));    // global minimum over the slabs
+    CFD_HIP(hipGetLastError());
+    return read_scalars(c, 0, 2, out);
 }
 
 static int finish_continuity(Ctx *c, int nb, double *out) {
