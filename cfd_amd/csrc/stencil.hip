@@ -457,6 +457,9 @@ static inline int red_blocks(int tiles) { return tiles < 2048 ? tiles : 2048; }
 //   MODE 0: continuity sum only            (13 planes read,            104 B/cell)
 //   MODE 1: b = -div F (pressure RHS)      (13 read, 1 written,        112 B/cell)
 //   MODE 2: momentum RHS b_u, b_v + the continuity sum of the same fluxes (13 (+k) read, 2 written)
+//   MODE 4: k / omega right-hand sides (solver.py:1109-1136, turbulence.py:427-444): Rhie-Chow flux with
+//           p_eff = p + 2/3 k, upwind advection of k and omega, Green-Gauss grad u, grad v for the production
+//           term, boundary terms with the transport conductances (ma.ai / ma.aj = t_i / t_j; ma.bu / ma.bv = b_k / b_omega)
 //   MODE 3: the two global minima of the adaptive time step (solver.py:547-582) from the plain interpolated
 //           fluxes (no Rhie-Chow term): u, v, 7 metric planes, lmin, nu_t read, 88 B/cell
 // ----------------------------------------------------------------------------------
@@ -482,7 +485,8 @@ struct FluxRow {
     double wri, nix, niy, si;      // west i-face of the cell
     double wnj, njx, njy, sj;      // south j-face of the cell
     double vol, k;
-    double lmin, nut;              // MODE 3 only
+    double lmin, nut;              // MODE 3 (MODE 4: nut)
+    double w;                      // MODE 4: omega
 };
 
 struct MomArgs {
@@ -490,8 +494,8 @@ struct MomArgs {
     double inv_dt, force_u, force_v;
     int per_i, per_j;
     double *bu, *bv;
-    // MODE 3 (time step)
-    const double *nut;
+    // MODE 3 (time step), MODE 4 (k / omega right-hand sides: nut, omega)
+    const double *nut, *omega;
     double nu, cfl, cfl_diff;
     int use_cfl, use_diff;
 };
@@ -522,6 +526,13 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 R.p = 0.0; R.ap = 1.0; R.si = 0.0; R.sj = 0.0; R.k = 0.0;
                 R.lmin = ma.use_diff ? m.lmin[c] : 1.0;
                 R.nut = ma.use_diff ? ma.nut[c] : 0.0;
+            } else if (MODE == 4) {
+                R.k = ma.kgrad[c];
+                R.w = ma.omega[c];
+                R.nut = ma.nut[c];
+                R.p = f.p[c] + (2.0 / 3.0) * R.k;        // p_eff (peff())
+                R.ap = rc ? f.ap[c] : 1.0;
+                R.si = m.si[c]; R.sj = m.sj[c];
             } else {
                 R.p = f.p[c];
                 R.ap = rc ? f.ap[c] : 1.0;
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
             }
         };
         FluxRow nxt, cur{}, prv{};
-        double u2 = 0.0, v2 = 0.0, p2 = 0.0, k2 = 0.0;      // row j-2 (MODE 2)
+        double u2 = 0.0, v2 = 0.0, p2 = 0.0, k2 = 0.0, w2 = 0.0;      // row j-2 (MODE 2, 4)
         double fw_p = 0.0, fs_p = 0.0;                       // west / south flux of row j-1
         fetch(j0 - 1, nxt);
         for (int j = j0 - 1; j <= j1; ++j) {
@@ -636,6 +647,68 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                     acc += div * div;
                 }
                 u2 = prv.u; v2 = prv.v; p2 = prv.p; k2 = prv.k;
+            } else if (MODE == 4) {
+                const double uW = lane_left(prv.u), uE = lane_right(prv.u);
+                const double vW = lane_left(prv.v), vE = lane_right(prv.v);
+                const double kW = lane_left(prv.k), kE = lane_right(prv.k);
+                const double wW = lane_left(prv.w), wE = lane_right(prv.w);
+                const double wriE = lane_right(prv.wri), nixE = lane_right(prv.nix), niyE = lane_right(prv.niy);
+                if (jo >= j0 && out) {
+                    const double fw = fw_p, fe = fe_p, fs = fs_p, fn = fs_c;
+                    const double vol = prv.vol;
+                    const size_t c = (size_t)(jo + NG) * P + colo;
+                    double advk, advw;
+                    {
+                        const double pc = prv.k;
+                        const double pw = fw >= 0.0 ? kW : pc, pe = fe >= 0.0 ? pc : kE;
+                        const double ps = fs >= 0.0 ? k2 : pc, pn = fn >= 0.0 ? pc : cur.k;
+                        const double div = fe * pe - fw * pw + fn * pn - fs * ps;
+                        advk = -div / vol;
+                    }
+                    {
+                        const double pc = prv.w;
+                        const double pw = fw >= 0.0 ? wW : pc, pe = fe >= 0.0 ? pc : wE;
+                        const double ps = fs >= 0.0 ? w2 : pc, pn = fn >= 0.0 ? pc : cur.w;
+                        const double div = fe * pe - fw * pw + fn * pn - fs * ps;
+                        advw = -div / vol;
+                    }
+                    double ux, uy, vx, vy;
+                    {
+                        const double pc = prv.u;
+                        const double pw = (1.0 - prv.wri) * uW + prv.wri * pc;
+                        const double pe = (1.0 - wriE) * pc + wriE * uE;
+                        const double ps = (1.0 - prv.wnj) * u2 + prv.wnj * pc;
+                        const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.u;
+                        ux = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
+                        uy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                    }
+                    {
+                        const double pc = prv.v;
+                        const double pw = (1.0 - prv.wri) * vW + prv.wri * pc;
+                        const double pe = (1.0 - wriE) * pc + wriE * vE;
+                        const double ps = (1.0 - prv.wnj) * v2 + prv.wnj * pc;
+                        const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.v;
+                        vx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
+                        vy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                    }
+                    const double s2 = 2.0 * (ux * ux) + 2.0 * (vy * vy) + (uy + vx) * (uy + vx);
+                    const double ks = fmax(prv.k, K_FLOOR), os = fmax(prv.w, OMEGA_FLOOR);
+                    const double srck = prv.nut * s2 - 0.09 * ks * os;
+                    const double srcw = (5.0 / 9.0) * s2 - (3.0 / 40.0) * (os * os);
+                    double b_k = vol * ma.inv_dt * prv.k + vol * (advk + srck);
+                    double b_w = vol * ma.inv_dt * prv.w + vol * (advw + srcw);
+                    if (!ma.per_i) {
+                        if (iraw == 0) { const double a = ma.ai[c]; b_k += a * kW; b_w += a * wW; }
+                        if (iraw == g.ni - 1) { const double a = ma.ai[c + 1]; b_k += a * kE; b_w += a * wE; }
+                    }
+                    if (!ma.per_j) {
+                        if (g.blo(jo)) { const double a = ma.aj[c]; b_k += a * k2; b_w += a * w2; }
+                        if (g.bhi(jo)) { const double a = ma.aj[c + P]; b_k += a * cur.k; b_w += a * cur.w; }
+                    }
+                    ma.bu[c] = b_k;
+                    ma.bv[c] = b_w;
+                }
+                u2 = prv.u; v2 = prv.v; k2 = prv.k; w2 = prv.w;
             } else if (MODE == 3) {
                 if (jo >= j0 && out) {
                     if (ma.use_cfl) {
@@ -819,6 +892,15 @@ __global__ void k_turb_rhs(Geo g, MeshDev m, FluxIn f, const double *om, const d
 
 int launch_turb_rhs(Ctx *c, double dt) {
     FluxIn f{c->U(), c->V(), c->P(), c->k, c->ap, c->rhie_chow};
+    if (c->march_flux) {
+        const FluxMarch fm = flux_march_geo(c->g);
+        MomArgs ma{c->k, c->ti, c->tj, 1.0 / dt, 0.0, 0.0, c->per_i, c->per_j, c->bu, c->bv};
+        ma.nut = c->nut; ma.omega = c->omega;
+        hipLaunchKernelGGL((k_flux_march<4, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
+                           (double *)nullptr, c->partials);
+        CFD_HIP(hipGetLastError());
+        return CFD_OK;
+    }
     hipLaunchKernelGGL(k_turb_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, c->omega,
                        c->nut, c->ti, c->tj, 1.0 / dt, c->per_i, c->per_j, c->bu, c->bv);
     CFD_HIP(hipGetLastError());

@@ -19,7 +19,10 @@ cells = float(sys.argv[2]) if len(sys.argv) > 2 else 8192.0 * 8192.0
 ALGO = {"k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 64, "k_mg_up<true>": 42, "k_mg_down<true>": 34, "k_mg_up_k<true, 3>": 42, "k_mg_down_k<true, 3>": 34, "k_cg_r": 24, "k_cg_init": 24,
         "k_cg_xlast": 24, "k_flux_march<0, false>": 104, "k_flux_march<1, false>": 112, "k_flux_march<2, false>": 120,
         "k_continuity": 104, "k_pressure_rhs": 112, "k_momentum_rhs": 120, "k_correct": 136, "k_diffusion_ap": 88,
-        "k_dt": 88, "k_rowsum_bound": 24, "k_pressure_coeffs": 64}
+        "k_dt": 88, "k_rowsum_bound": 24, "k_pressure_coeffs": 64, "k_flux_march<3, false>": 88,
+        # k-omega variant
+        "k_flux_march<2, true>": 128, "k_turb_rhs": 144, "k_komega_coeffs<true>": 136, "k_komega_coeffs<false>": 112, "k_clip": 16,
+        "k_eddy_viscosity": 24}
 KNOWN_READS = {"k_cg_r": 16.0, "k_cg_xlast": 16.0, "k_cg_init": 8.0}      # calibration kernels
 
 
