@@ -10,13 +10,13 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
 
 The JSON line also carries
   roofline     : the kernel with the largest share of device time, k_chebk<2,4> (momentum solve: four fused
-                 Jacobi-Chebyshev iterations of u and v per launch; 14-15 % in profiles/r1l_*), timed live with
+                 Jacobi-Chebyshev iterations of u and v per launch; 14-15 % in profiles/r1m_*), timed live with
                  HIP-event pairs around every launch inside the timed steps; achieved = 104 B/cell * Ni*Nj /
                  avg duration (x_k, x_k-1, b of both right-hand sides, D, c_i, c_j read; two iterates of each
                  written).  --probe 0 / 7 / 1 / 2 / 9 select the PCG direction step k_cg_pq (14.6-14.9 %), the
                  multigrid up / down kernels, the momentum RHS kernel or the single-RHS Chebyshev kernel.
                  traffic = HBM bytes per launch from the committed PMC passes of this command
-                 (profiles/r1l_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
+                 (profiles/r1m_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
                  were measured on.
   strong_scaling_leg (N > 1): after the timed region the same --size x --size channel is split over the N GPUs and
                  timed the same way; its value / the 1-GPU value is the strong-scaling speed-up.  The headline stays
@@ -41,8 +41,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
-# 8192^2 (profiles/r1l_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.33, 9: 70.52, 7: 41.65, 1: 33.87, 2: 117.50}
+# 8192^2 (profiles/r1m_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.33, 9: 70.53, 7: 41.65, 1: 33.87, 2: 117.70}
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None):

@@ -21,7 +21,7 @@ ALGO = {"k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 64, "k_mg_up<true>
         "k_continuity": 104, "k_pressure_rhs": 112, "k_momentum_rhs": 120, "k_correct": 136, "k_diffusion_ap": 88,
         "k_dt": 88, "k_rowsum_bound": 24, "k_pressure_coeffs": 64, "k_flux_march<3, false>": 88,
         # k-omega variant
-        "k_flux_march<2, true>": 128, "k_turb_rhs": 144, "k_komega_coeffs<true>": 136, "k_komega_coeffs<false>": 112, "k_clip": 16,
+        "k_flux_march<2, true>": 128, "k_turb_rhs": 144, "k_flux_march<4, false>": 144, "k_komega_coeffs<true>": 136, "k_komega_coeffs<false>": 112, "k_clip": 16,
         "k_eddy_viscosity": 24}
 KNOWN_READS = {"k_cg_r": 16.0, "k_cg_xlast": 16.0, "k_cg_init": 8.0}      # calibration kernels
 
