@@ -187,6 +187,7 @@ struct cfd_ctx {
 #define CTX_MUT(ctx)       \
     CTX(ctx)               \
     c->rhs_ahead = false;  \
+    c->dt_ahead = false;   \
     c->ap_cached = false;
 
 #define NEED_MESH()                                                           \
@@ -580,6 +581,7 @@ int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double
     if (const char *e = getenv("CFD_CHEB_STAGES")) c->cheb_stages = atoi(e);      // tuning / A-B measurements
     if (const char *e = getenv("CFD_MARCH_FLUX")) c->march_flux = atoi(e);
     if (const char *e = getenv("CFD_FUSE_NUT")) c->fuse_nut = atoi(e);
+    if (const char *e = getenv("CFD_DT_LOOKAHEAD")) c->dt_lookahead = atoi(e);
     if (const char *e = getenv("CFD_RHS_LOOKAHEAD")) c->rhs_lookahead = atoi(e);
     return CFD_OK;
 }
@@ -862,6 +864,7 @@ int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, dou
     CTX(ctx);
     CFD_TRY(ready(c));
     if (!(dt > 0.0)) { set_error("dt must be positive"); return CFD_E_ARG; }
+    c->dt_ahead = false;
     CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
     CFD_TRY(do_predictor(c, dt, res));
     CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P()));
@@ -882,6 +885,7 @@ int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, dou
     CTX(ctx);
     CFD_TRY(ready(c));
     if (!(dt > 0.0) || n_correctors < 1) { set_error("cfd_piso_step: bad arguments"); return CFD_E_ARG; }
+    c->dt_ahead = false;
     CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
     CFD_TRY(do_predictor(c, dt, res));
     CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P()));

@@ -221,6 +221,11 @@ struct Ctx {
     int cheb_max_iters = 80;     // ... and predicted iteration count below this; else BiCGStab
     int stats_last_solver = 0;   // 1 = the last transport solve was Chebyshev
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
+    // time-step minima of the next outer step evaluated by the pass that closes an inner iteration (laminar runs)
+    int dt_lookahead = 1;
+    bool dt_ahead = false, dtp_set = false;
+    int dt_ahead_cur = 0, dtp_use_cfl = 0, dtp_use_diff = 0;
+    double dtp_cfl = 0.0, dtp_cfl_diff = 0.0;
     int fuse_nut = 1;            // k-omega: eddy viscosity evaluated inside the conductance pass (k_komega_coeffs)
     int march_flux = 1;          // marching form of the Rhie-Chow flux kernels (momentum / pressure RHS, continuity)
     // momentum right-hand sides computed ahead of time by the fused continuity pass of the previous

@@ -460,6 +460,9 @@ static inline int red_blocks(int tiles) { return tiles < 2048 ? tiles : 2048; }
 //   MODE 4: k / omega right-hand sides (solver.py:1109-1136, turbulence.py:427-444): Rhie-Chow flux with
 //           p_eff = p + 2/3 k, upwind advection of k and omega, Green-Gauss grad u, grad v for the production
 //           term, boundary terms with the transport conductances (ma.ai / ma.aj = t_i / t_j; ma.bu / ma.bv = b_k / b_omega)
+//   MODE 2 with DT: additionally the two time-step minima of MODE 3 for the NEXT outer step, from the interpolated
+//           part of the same face fluxes (the fields of a finished iteration are the fields compute_adaptive_dt
+//           sees at the start of the next step); +lmin read, laminar runs only (nu_t changes in between otherwise)
 //   MODE 3: the two global minima of the adaptive time step (solver.py:547-582) from the plain interpolated
 //           fluxes (no Rhie-Chow term): u, v, 7 metric planes, lmin, nu_t read, 88 B/cell
 // ----------------------------------------------------------------------------------
@@ -500,14 +503,14 @@ struct MomArgs {
     int use_cfl, use_diff;
 };
 
-template <int MODE, bool KG>
+template <int MODE, bool KG, bool DT = false>
 __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, FluxMarch fm, MomArgs ma, double *bout,
                                                     double *partials) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     const int rc = MODE == 3 ? 0 : f.rc;
-    double acc = MODE == 3 ? INFINITY : 0.0, acc2 = INFINITY;
+    double acc = MODE == 3 ? INFINITY : 0.0, acc2 = INFINITY, acc3 = INFINITY;
     for (int item = blockIdx.x * 4 + wave; item < fm.nstrips * fm.nsegs; item += nw) {
         const int strip = item % fm.nstrips, seg = item / fm.nstrips;
         const int iraw = strip * FXW - 1 + lane;          // -1 .. ni : ghost columns included
@@ -538,23 +541,26 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 R.ap = rc ? f.ap[c] : 1.0;
                 R.si = m.si[c]; R.sj = m.sj[c];
                 R.k = KG ? (2.0 / 3.0) * ma.kgrad[c] : 0.0;
+                if (DT) R.lmin = ma.use_diff ? m.lmin[c] : 1.0;
             }
         };
         FluxRow nxt, cur{}, prv{};
         double u2 = 0.0, v2 = 0.0, p2 = 0.0, k2 = 0.0, w2 = 0.0;      // row j-2 (MODE 2, 4)
         double fw_p = 0.0, fs_p = 0.0;                       // west / south flux of row j-1
+        double lw_p = 0.0, ls_p = 0.0;                       // their interpolated parts (DT)
         fetch(j0 - 1, nxt);
         for (int j = j0 - 1; j <= j1; ++j) {
             cur = nxt;
             if (j < j1) fetch(j + 1, nxt);
             // west-face flux of row j (flux_i)
             const double uL = lane_left(cur.u), vL = lane_left(cur.v), pL = lane_left(cur.p);
-            double fw_c;
+            double fw_c, lw_c, ls_c;
             {
                 const double wr = cur.wri, wl = 1.0 - wr;
                 const double ui = wl * uL + wr * cur.u;
                 const double vi = wl * vL + wr * cur.v;
                 fw_c = ui * cur.nix + vi * cur.niy;
+                lw_c = fw_c;
                 if (rc) {
                     const double apL = lane_left(cur.ap);
                     double af = ilo ? cur.ap : (ihi ? apL : wl * apL + wr * cur.ap);
@@ -571,6 +577,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 const double uj = ws * prv.u + wn * cur.u;
                 const double vj = ws * prv.v + wn * cur.v;
                 fs_c = uj * cur.njx + vj * cur.njy;
+                ls_c = fs_c;
                 if (rc) {
                     double af = lo ? cur.ap : (hi ? prv.ap : ws * prv.ap + wn * cur.ap);
                     af = af > TINY ? af : TINY;
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
             // output row jo = j - 1: cell data in prv, north neighbour in cur, south neighbour in *2
             const int jo = j - 1;
             const double fe_p = lane_right(fw_p);
+            const double le_p = DT ? lane_right(lw_p) : 0.0;
             if (MODE == 2) {
                 // DPP shifts must run in all lanes: hoisted out of the output branch
                 const double uW = lane_left(prv.u), uE = lane_right(prv.u);
@@ -645,6 +653,19 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                     ma.bv[c] = b_v;
                     const double div = (fe - fw + fn - fs) / vol;
                     acc += div * div;
+                    if (DT) {
+                        if (ma.use_cfl) {
+                            const double tot = fabs(lw_p) + fabs(le_p) + fabs(ls_p) + fabs(ls_c);
+                            const double safe = tot > TINY ? tot : TINY;
+                            acc2 = fmin(acc2, ma.cfl * vol / safe);
+                        }
+                        if (ma.use_diff) {
+                            const double ne = ma.nu + 0.0;      // laminar: the nu_t plane is zero
+                            const double ns = ne > 0.0 ? ne : TINY;
+                            const double l = prv.lmin;
+                            acc3 = fmin(acc3, ma.cfl_diff * (l * l) / ns);
+                        }
+                    }
                 }
                 u2 = prv.u; v2 = prv.v; p2 = prv.p; k2 = prv.k;
             } else if (MODE == 4) {
@@ -730,6 +751,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 else { const double bv = vol * (-div); bout[(size_t)(jo + NG) * P + colo] = bv; acc += bv; }   // sum b (nullspace form)
             }
             fw_p = fw_c; fs_p = fs_c;
+            lw_p = lw_c; ls_p = ls_c;
             prv = cur;
         }
     }
@@ -743,15 +765,33 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
             partials[MAX_PARTIALS + blockIdx.x] = fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3]));
         }
     } else {
-        __shared__ double sm[4];
+        __shared__ double sm[4], sa[4], sb[4];
         const double w = wave_sum(acc);
-        if (lane == 0) sm[wave] = w;
+        const double wa = DT ? wave_min(acc2) : 0.0, wb = DT ? wave_min(acc3) : 0.0;
+        if (lane == 0) { sm[wave] = w; if (DT) { sa[wave] = wa; sb[wave] = wb; } }
         __syncthreads();
-        if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        if (threadIdx.x == 0) {
+            partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+            if (DT) {
+                partials[MAX_PARTIALS + blockIdx.x] = fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3]));
+                partials[2 * MAX_PARTIALS + blockIdx.x] = fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3]));
+            }
+        }
     }
 }
 
+constexpr int DT_AHEAD_OFF = 96;      // Ctx::scal slots of the time-step minima computed ahead
+
 int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]) {
+    const bool same = c->dtp_set && c->dtp_use_cfl == use_cfl && c->dtp_use_diff == use_cfl_diff && c->dtp_cfl == cfl &&
+                      c->dtp_cfl_diff == cfl_diff;
+    c->dtp_set = true; c->dtp_use_cfl = use_cfl; c->dtp_use_diff = use_cfl_diff; c->dtp_cfl = cfl; c->dtp_cfl_diff = cfl_diff;
+    if (c->dt_ahead && same && c->dt_ahead_cur == c->cur && !c->turbulent) {
+        // the last finished iteration evaluated both minima of these very fields (k_flux_march<2, ., DT>)
+        c->dt_ahead = false;
+        CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF, 2, 1));
+        return read_scalars(c, DT_AHEAD_OFF, 2, out);
+    }
     int nb;
     if (c->march_flux) {
         // marching form: every row of u, v and of the metric planes is read once (88 instead of ~117 B/cell)
@@ -834,12 +874,24 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         // marching kernel: the continuity sum of the same fluxes comes for free (cont != nullptr reads it)
         const FluxMarch fm = flux_march_geo(c->g);
         MomArgs ma{c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j, c->bu, c->bv};
-        if (c->turbulent)
+        // cont != nullptr: the pass that closes an inner iteration -- in laminar runs it also evaluates the time-step
+        // minima the next outer step will ask for (same fields; parameters of the last cfd_compute_dt call)
+        const bool dt_too = cont && !c->turbulent && c->dt_lookahead && c->dtp_set;
+        if (c->turbulent) {
             hipLaunchKernelGGL((k_flux_march<2, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
                                (double *)nullptr, c->partials);
-        else
+        } else if (dt_too) {
+            ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl; ma.use_diff = c->dtp_use_diff;
+            hipLaunchKernelGGL((k_flux_march<2, false, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
+                               (double *)nullptr, c->partials);
+            hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials + MAX_PARTIALS, fm.blocks, 2,
+                               c->scal + DT_AHEAD_OFF);
+            c->dt_ahead = true;
+            c->dt_ahead_cur = c->cur;
+        } else {
             hipLaunchKernelGGL((k_flux_march<2, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
                                (double *)nullptr, c->partials);
+        }
         CFD_HIP(hipGetLastError());
         if (cont) return finish_continuity(c, fm.blocks, cont);
         return CFD_OK;

@@ -544,6 +544,37 @@ def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path, monkeypat
     assert np.array_equal(out["0"][1], out["1"][1])
 
 
+@pytest.mark.parametrize("name,schedule", [("channel_forced_24", None), ("inlet_outlet_channel", None),
+                                           ("channel_forced_24", [(0.2, 0), (0.6, 3)])])
+def test_time_step_minima_computed_ahead(name, schedule, tmp_path, monkeypatch):
+    """Laminar runs: the pass that closes an inner iteration also evaluates the CFL / diffusive minima of the next
+    outer step (same fields).  Times, fields and logs keep the bits of the separate time-step kernel; with a CFL
+    schedule the parameters differ from step to step and the values computed ahead must be discarded."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    out = {}
+    for ahead in ("0", "1"):
+        monkeypatch.setenv("CFD_DT_LOOKAHEAD", ahead)
+        d = tmp_path / f"ahead{ahead}"
+        builder, fixup = cases.ALL_END_TO_END[name]
+        cfg, mp, kind = builder()
+        gen = hip_mesh.generate_rect_mesh if kind == "rect" else hip_mesh.generate_annulus_mesh
+        cfg["mesh"] = {"generator": gen, "params": mp, "path": d / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": d, "mesh_dir": d / "mesh", "states_dir": d / "states", "post_dir": d / "postproc"}
+        cfg["time"]["max_steps"] = 5
+        if schedule is not None:
+            cfg["time"]["cfl_schedule"] = schedule
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        if fixup is not None:
+            fixup(cfg, mesh)
+        fields, step, time = hip_solver.run_case(cfg)
+        out[ahead] = (fields, time, np.loadtxt(d / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2))
+    assert out["0"][1] == out["1"][1] and out["0"][1] > 0.0
+    for key in out["0"][0]:
+        assert np.array_equal(out["0"][0][key], out["1"][0][key]), key
+    assert np.array_equal(out["0"][2], out["1"][2])
+
+
 def test_committed_reference_sst_run(tmp_path):
     """Tier A for the SST closure: the reference's own committed 5x20 SST run (real pyamg, rtol 1e-8):
     first logged steps of the residual / friction logs and states/sst/fields_000000.npz with its caches."""
