@@ -20,6 +20,9 @@ ALGO = {"k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 64, "k_mg_up<true>
         "k_cg_xlast": 24, "k_flux_march<0, false>": 104, "k_flux_march<1, false>": 112, "k_flux_march<2, false>": 120,
         "k_continuity": 104, "k_pressure_rhs": 112, "k_momentum_rhs": 120, "k_correct": 136, "k_diffusion_ap": 88,
         "k_dt": 88, "k_rowsum_bound": 24, "k_pressure_coeffs": 64, "k_flux_march<3, false>": 88,
+        "k_flux_march<0, false, false>": 104, "k_flux_march<1, false, false>": 112, "k_flux_march<2, false, false>": 120,
+        "k_flux_march<2, false, true>": 128, "k_flux_march<3, false, false>": 88, "k_flux_march<2, true, false>": 128,
+        "k_flux_march<4, false, false>": 144,
         # k-omega variant
         "k_flux_march<2, true>": 128, "k_turb_rhs": 144, "k_flux_march<4, false>": 144, "k_komega_coeffs<true>": 136, "k_komega_coeffs<false>": 112, "k_clip": 16,
         "k_eddy_viscosity": 24}
