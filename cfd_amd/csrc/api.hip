@@ -582,6 +582,7 @@ int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double
     if (const char *e = getenv("CFD_MARCH_FLUX")) c->march_flux = atoi(e);
     if (const char *e = getenv("CFD_FUSE_NUT")) c->fuse_nut = atoi(e);
     if (const char *e = getenv("CFD_DT_LOOKAHEAD")) c->dt_lookahead = atoi(e);
+    if (const char *e = getenv("CFD_FUSE_RESID")) c->fuse_resid = atoi(e);
     if (const char *e = getenv("CFD_RHS_LOOKAHEAD")) c->rhs_lookahead = atoi(e);
     return CFD_OK;
 }

@@ -226,6 +226,7 @@ struct Ctx {
     bool dt_ahead = false, dtp_set = false;
     int dt_ahead_cur = 0, dtp_use_cfl = 0, dtp_use_diff = 0;
     double dtp_cfl = 0.0, dtp_cfl_diff = 0.0;
+    int fuse_resid = 1;          // PCG: r = r - alpha q formed by the next V-cycle's pre-smoother on unchecked iterations
     int fuse_nut = 1;            // k-omega: eddy viscosity evaluated inside the conductance pass (k_komega_coeffs)
     int march_flux = 1;          // marching form of the Rhie-Chow flux kernels (momentum / pressure RHS, continuity)
     // momentum right-hand sides computed ahead of time by the fused continuity pass of the previous

@@ -885,15 +885,24 @@ struct SweepOm {
 };
 
 struct MgRaw {
-    double b, d, cw, ce, cs, cn, x, e;
+    double b, d, cw, ce, cs, cn, x, e, q;
     int row;
     bool valid;
 };
 
-template <bool UP>
+// The PCG residual update r = r_old - alpha q folded into the finest-level pre-smoother (k_mg_down_k<true, K, true>):
+// the kernel reads r_old and q where it would read its right-hand side, forms r in registers and stores the rows it
+// owns to `rnew` (a different plane than r_old: the halo rows of a segment are the neighbouring segments' own rows).
+struct ResidFuse {
+    const double *q;
+    const double *rz, *pq;       // alpha = rz / pq (CgScal of the running solve)
+    double *rnew;
+};
+
+template <bool UP, bool RF = false>
 __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, const Geo &g, const Geo &gc, const double *b,
                                          const double *x, const double *e, int j, bool cvalid, size_t colo, size_t coloc,
-                                         MgRaw &R) {
+                                         MgRaw &R, const double *q = nullptr) {
     const size_t P = g.pitch;
     const int mr = mem_row(j, g, op.per_j);
     R.valid = cvalid && mr >= 0;
@@ -904,6 +913,7 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
         R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
     R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+    if (RF) R.q = q[cc];
     R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
     R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
     R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
@@ -913,10 +923,11 @@ __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const 
     return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
 }
 
-template <bool FINE, int K>
+template <bool FINE, int K, bool RF = false>
 __global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
-                                                   Geo gc, double *bc) {
+                                                   Geo gc, double *bc, ResidFuse rf = ResidFuse{}) {
     const Geo g = op.g;
+    const double alpha = RF ? safe_div(rf.rz[0], rf.pq[0]) : 0.0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
@@ -941,10 +952,14 @@ __global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFi
         }
         double rsum = 0.0;
         MgRaw nxt;
-        mg_fetch<false>(op, df, g, gc, b, nullptr, nullptr, j0 - K, cvalid, colo, 0, nxt);
+        mg_fetch<false, RF>(op, df, g, gc, b, nullptr, nullptr, j0 - K, cvalid, colo, 0, nxt, rf.q);
         for (int j = j0 - K; j < j1 + K; ++j) {
-            const MgRaw cur = nxt;
-            if (j + 1 < j1 + K) mg_fetch<false>(op, df, g, gc, b, nullptr, nullptr, j + 1, cvalid, colo, 0, nxt);
+            MgRaw cur = nxt;
+            if (j + 1 < j1 + K) mg_fetch<false, RF>(op, df, g, gc, b, nullptr, nullptr, j + 1, cvalid, colo, 0, nxt, rf.q);
+            if (RF) {
+                cur.b = cur.b - alpha * cur.q;                               // k_cg_r's expression
+                if (j >= j0 && j < j1 && out) rf.rnew[(size_t)(j + NG) * P + colo] = cur.b;
+            }
             RC[0] = mg_row(cur, df, op, colo);
             V[0] = cur.valid;
             X[1][2] = V[0] ? om.w[0] * RC[0].b * RC[0].inv : 0.0;          // first sweep from a zero guess
@@ -1794,7 +1809,8 @@ int build_pressure_hierarchy(Ctx *c) {
 
 // One V-cycle: z ~= A^-1 r starting from zero.  The result lands in *zout, which is
 // either z0 or z1 (Jacobi ping-pong).
-static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks) {
+static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks,
+                       const ResidFuse *rf = nullptr) {
     hipStream_t st = c->stream;
     const int nl = (int)c->levels.size();
     // sweep s of a smoothing pass uses omega (even s) or omega2 (odd s): with omega2 != omega the two
@@ -1829,15 +1845,22 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
             if (!rhs_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
-            if (l == 0) {
+            if (l == 0 && rf) {
+                // rhs[0] is r_old here; the kernel leaves r = r_old - alpha q in rf->rnew, which the way up reads
+                if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
+                c->probe_begin(1);
+                hipLaunchKernelGGL((k_mg_down_k<true, 3, true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf);
+                c->probe_end(1);
+                rhs[0] = rf->rnew;
+            } else if (l == 0) {
                 c->probe_begin(1);
                 if (KS == 3)
-                    hipLaunchKernelGGL((k_mg_down_k<true, 3>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb);
+                    hipLaunchKernelGGL((k_mg_down_k<true, 3>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{});
                 else
                     hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
                 c->probe_end(1);
             } else if (KS == 3) {
-                hipLaunchKernelGGL((k_mg_down_k<false, 3>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb);
+                hipLaunchKernelGGL((k_mg_down_k<false, 3>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{});
             } else {
                 hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om, om2, cur[l], cg, cb);
             }
@@ -2176,11 +2199,26 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     }
     rr = bb;
     int it = 0;
+    // Iterations whose |r| the host does not look at leave r = r - alpha q to the pre-smoother of the next V-cycle
+    // (k_mg_down_k<true, 3, true>): r ping-pongs between the right-hand side plane and kry[1].  Single-rank contexts
+    // with the three-sweep marching kernels on the finest level.
+    const bool can_defer = c->fuse_resid && fused && c->comm.nranks <= 1 && c->levels.size() > 1 && c->mg_pre == 3 && c->mg_post == 3 &&
+                           level_fusable(c, L0.g, coarse_view(c, 1));
+    double *r_other = c->kry[1];
+    bool deferred = false;
+    int deferred_gen = 0;
     while (it < maxiter) {
         const int gen = it & 1;
         double *z = nullptr;
         int db = 0;
-        CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db));
+        if (deferred) {
+            const ResidFuse rf{q, &S->rz[deferred_gen], &S->pq, r_other};
+            CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db, &rf));
+            std::swap(r, r_other);
+            deferred = false;
+        } else {
+            CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db));
+        }
         if (db > 0) {
             CFD_TRY(finish_to(c, db, 1, CG_OFF_OF(rz[gen])));     // (r, z) came out of the fused up-sweep
         } else {
@@ -2198,6 +2236,12 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             c->probe_end(0);
             CFD_HIP(hipGetLastError());
             CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));
+            if (can_defer && it + 3 < c->p_iters_hint && it + 1 < maxiter) {
+                deferred = true;               // the next V-cycle forms r itself; nobody reads |r| of this iteration
+                deferred_gen = gen;
+                ++it;
+                continue;
+            }
             hipLaunchKernelGGL(k_cg_r, grid, blk, 0, st, g, T, S, gen, q, r, c->partials);
         } else {
             hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);

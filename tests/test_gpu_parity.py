@@ -575,6 +575,33 @@ def test_time_step_minima_computed_ahead(name, schedule, tmp_path, monkeypatch):
     assert np.array_equal(out["0"][2], out["1"][2])
 
 
+@pytest.mark.parametrize("name", ["channel_forced_24", "half_cylinder_komega"])
+def test_residual_update_inside_the_presmoother(name, tmp_path, monkeypatch):
+    """MG-PCG iterations whose |r| the host does not look at leave r = r - alpha q to the pre-smoother of the next
+    V-cycle (k_mg_down_k<true, 3, true>): same bits as the separate k_cg_r pass, same iteration counts."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("CFD_FUSE_RESID", fuse)
+        d = tmp_path / f"fuse{fuse}"
+        builder, fixup = cases.ALL_END_TO_END[name]
+        cfg, mp, kind = builder()
+        gen = hip_mesh.generate_rect_mesh if kind == "rect" else hip_mesh.generate_annulus_mesh
+        cfg["mesh"] = {"generator": gen, "params": mp, "path": d / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": d, "mesh_dir": d / "mesh", "states_dir": d / "states", "post_dir": d / "postproc"}
+        cfg["time"]["max_steps"] = 6
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        if fixup is not None:
+            fixup(cfg, mesh)
+        fields, step, time = hip_solver.run_case(cfg)     # tight tolerances: 8+ PCG iterations per solve, several deferred
+        out[fuse] = (fields, time, np.loadtxt(d / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2))
+    assert out["0"][1] == out["1"][1]
+    for key in out["0"][0]:
+        assert np.array_equal(out["0"][0][key], out["1"][0][key]), key
+    assert np.array_equal(out["0"][2], out["1"][2])
+
+
 def test_committed_reference_sst_run(tmp_path):
     """Tier A for the SST closure: the reference's own committed 5x20 SST run (real pyamg, rtol 1e-8):
     first logged steps of the residual / friction logs and states/sst/fields_000000.npz with its caches."""
