@@ -958,7 +958,10 @@ __global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFi
             if (j + 1 < j1 + K) mg_fetch<false, RF>(op, df, g, gc, b, nullptr, nullptr, j + 1, cvalid, colo, 0, nxt, rf.q);
             if (RF) {
                 cur.b = cur.b - alpha * cur.q;                               // k_cg_r's expression
-                if (j >= j0 && j < j1 && out) rf.rnew[(size_t)(j + NG) * P + colo] = cur.b;
+                // own rows, and at a slab cut the ghost rows next to the first / last segment (formed from the neighbour's
+                // r_old and q rows, they are the neighbour's r): the way up reads them
+                const bool own = (j >= j0 && j < j1) || (g.cutlo && j < 0 && j0 == 0) || (g.cuthi && j >= g.nj && j1 == g.nj);
+                if (own && out) rf.rnew[(size_t)(j + NG) * P + colo] = cur.b;
             }
             RC[0] = mg_row(cur, df, op, colo);
             V[0] = cur.valid;
@@ -1844,7 +1847,8 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (level_fusable(c, L.g, cg)) {
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
-            if (!rhs_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
+            if (l == 0 && rf) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rf->q)));      // r_old's rows are there already
+            else if (!rhs_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
             if (l == 0 && rf) {
                 // rhs[0] is r_old here; the kernel leaves r = r_old - alpha q in rf->rnew, which the way up reads
                 if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
@@ -2200,9 +2204,9 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     rr = bb;
     int it = 0;
     // Iterations whose |r| the host does not look at leave r = r - alpha q to the pre-smoother of the next V-cycle
-    // (k_mg_down_k<true, 3, true>): r ping-pongs between the right-hand side plane and kry[1].  Single-rank contexts
-    // with the three-sweep marching kernels on the finest level.
-    const bool can_defer = c->fuse_resid && fused && c->comm.nranks <= 1 && c->levels.size() > 1 && c->mg_pre == 3 && c->mg_post == 3 &&
+    // (k_mg_down_k<true, 3, true>): r ping-pongs between the right-hand side plane and kry[1].  Needs the three-sweep
+    // marching kernels on the finest level; on j-slabs q crosses the cuts in place of r.
+    const bool can_defer = c->fuse_resid && fused && c->levels.size() > 1 && c->mg_pre == 3 && c->mg_post == 3 &&
                            level_fusable(c, L0.g, coarse_view(c, 1));
     double *r_other = c->kry[1];
     bool deferred = false;
