@@ -10,13 +10,13 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
 
 The JSON line also carries
   roofline     : the kernel with the largest share of device time, k_chebk<2,4> (momentum solve: four fused
-                 Jacobi-Chebyshev iterations of u and v per launch; 14-15 % in profiles/r1n_*), timed live with
+                 Jacobi-Chebyshev iterations of u and v per launch; 14-15 % in profiles/r1o_*), timed live with
                  HIP-event pairs around every launch inside the timed steps; achieved = 104 B/cell * Ni*Nj /
                  avg duration (x_k, x_k-1, b of both right-hand sides, D, c_i, c_j read; two iterates of each
                  written).  --probe 0 / 7 / 1 / 2 / 9 select the PCG direction step k_cg_pq (14.6-14.9 %), the
                  multigrid up / down kernels, the momentum RHS kernel or the single-RHS Chebyshev kernel.
                  traffic = HBM bytes per launch from the committed PMC passes of this command
-                 (profiles/r1n_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
+                 (profiles/r1o_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
                  were measured on.
   strong_scaling_leg (N > 1): after the timed region the same --size x --size channel is split over the N GPUs and
                  timed the same way; its value / the 1-GPU value is the strong-scaling speed-up.  The headline stays
@@ -41,8 +41,8 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
-# 8192^2 (profiles/r1n_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.32, 9: 70.53, 7: 41.65, 1: 33.87, 2: 126.07}
+# 8192^2 (profiles/r1o_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.32, 9: 70.53, 7: 41.65, 1: 33.87, 10: 49.93, 2: 126.08}
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None):
@@ -124,7 +124,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--probe", type=int, default=8, help="kernel id for the live roofline probe (8 = momentum Chebyshev, "
-                    "0 = PCG direction step, 7 / 1 = multigrid up / down, 2 = momentum RHS, 9 = single-RHS Chebyshev)")
+                    "0 = PCG direction step, 7 / 1 / 10 = multigrid up / down / down with residual update, 2 = momentum RHS, "
+                    "9 = single-RHS Chebyshev)")
     ap.add_argument("--mg-sweeps", type=int, default=None, help="pre = post smoothing sweeps (2 or 3)")
     ap.add_argument("--mg-omegas", type=str, default=None, help="comma-separated damping factors, used cyclically")
     ap.add_argument("--mg-omega", type=float, default=None, help="smoother damping of the even sweeps")
@@ -222,7 +223,7 @@ def main():
     # the other kernels BASELINE.json's target names (momentum RHS / Rhie-Chow, MG smoother, PCG step): one more
     # step each with the event-pair probe on that kernel
     others = {}
-    for pid in (2, 1, 7, 0, 8):
+    for pid in (2, 1, 10, 7, 0, 8):
         if pid == args.probe:
             continue
         dev.probe(pid)
@@ -285,8 +286,9 @@ def main():
                         2: "momentum RHS + continuity sum (+ next step's time-step minima in laminar runs, + grad(2/3 k) in k-omega runs), marching Rhie-Chow flux kernel (k_flux_march<2>)", 3: "batched momentum operator (k_bi_apply<2>)",
                         8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>)",
                         9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
+                        10: "MG pre-smoother with the PCG residual update folded in (k_mg_down_k<true,3,true>)",
                         7: "MG post-smoother, finest level: prolong + 3 fused Jacobi sweeps + (r,z) (k_mg_up_k<true,3>)"}
-        bpc_table = {0: 64, 1: 34, 2: 128, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104, 9: 64}
+        bpc_table = {0: 64, 1: 34, 10: 50, 2: 128, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104, 9: 64}
         bytes_per_cell = bpc_table[args.probe]
         achieved = bytes_per_cell * cells_gpu / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

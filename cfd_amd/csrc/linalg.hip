@@ -1852,9 +1852,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             if (l == 0 && rf) {
                 // rhs[0] is r_old here; the kernel leaves r = r_old - alpha q in rf->rnew, which the way up reads
                 if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
-                c->probe_begin(1);
+                c->probe_begin(10);
                 hipLaunchKernelGGL((k_mg_down_k<true, 3, true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf);
-                c->probe_end(1);
+                c->probe_end(10);
                 rhs[0] = rf->rnew;
             } else if (l == 0) {
                 c->probe_begin(1);

@@ -337,8 +337,10 @@ int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, in
  * 2 = momentum RHS, 3 = batched momentum SpMV, 4 = residual+restrict, 5 = continuity        */
 int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us);
 /* live probe: record a HIP-event pair on the context stream around EVERY launch of one hot
- * kernel (same ids as cfd_time_kernel; -1 = off) while the solver runs, up to 4096 launches;
- * cfd_probe_read returns how many launches were timed and their average duration.        */
+ * kernel while the solver runs, up to 4096 launches (-1 = off): 0 = PCG direction step, 1 = finest-level
+ * multigrid pre-smoother pass, 10 = the same with the PCG residual update folded in, 7 = post-smoother pass,
+ * 2 = momentum right-hand sides (+ continuity, + time-step minima), 8 / 9 = Chebyshev launches with two / one
+ * right-hand sides.  cfd_probe_read returns how many launches were timed and their average duration.        */
 int cfd_probe(cfd_ctx *ctx, int kernel);
 int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us);
 /* accumulated device time per phase since the last reset (HIP events), microseconds:
