@@ -1007,7 +1007,10 @@ int cfd_sst_set_cached(cfd_ctx *ctx, int cached) {
 }
 
 int cfd_turbulence_step(cfd_ctx *ctx, double dt) {
-    CTX_MUT(ctx);
+    // k, omega, nu_t change; u, v do not: the advective time-step minimum taken ahead stays valid
+    CTX(ctx);
+    c->rhs_ahead = false;
+    c->dt_ahead_diff = false;
     CFD_TRY(ready(c));
     if (!c->turbulent) { set_error("turbulence is disabled"); return CFD_E_STATE; }
     Phase ph(c, PH_TURB);

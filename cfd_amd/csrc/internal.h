@@ -223,7 +223,7 @@ struct Ctx {
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
     // time-step minima of the next outer step evaluated by the pass that closes an inner iteration (laminar runs)
     int dt_lookahead = 1;
-    bool dt_ahead = false, dtp_set = false;
+    bool dt_ahead = false, dt_ahead_diff = false, dtp_set = false;
     int dt_ahead_cur = 0, dtp_use_cfl = 0, dtp_use_diff = 0;
     double dtp_cfl = 0.0, dtp_cfl_diff = 0.0;
     int fuse_resid = 1;          // PCG: r = r - alpha q formed by the next V-cycle's pre-smoother on unchecked iterations

@@ -786,9 +786,19 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
     const bool same = c->dtp_set && c->dtp_use_cfl == use_cfl && c->dtp_use_diff == use_cfl_diff && c->dtp_cfl == cfl &&
                       c->dtp_cfl_diff == cfl_diff;
     c->dtp_set = true; c->dtp_use_cfl = use_cfl; c->dtp_use_diff = use_cfl_diff; c->dtp_cfl = cfl; c->dtp_cfl_diff = cfl_diff;
-    if (c->dt_ahead && same && c->dt_ahead_cur == c->cur && !c->turbulent) {
-        // the last finished iteration evaluated both minima of these very fields (k_flux_march<2, ., DT>)
+    if (c->dt_ahead && same && c->dt_ahead_cur == c->cur) {
+        // the last finished iteration evaluated the minima of these very fields (k_flux_march<2, ., DT>); in k-omega /
+        // SST runs nu_t has changed since, so the diffusive one is taken now (nu_t and lmin only: 16 B/cell)
         c->dt_ahead = false;
+        if (use_cfl_diff && !c->dt_ahead_diff) {
+            int tx;
+            const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
+            hipLaunchKernelGGL(k_dt, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), c->U(), c->V(), c->nut, c->nu, 0, cfl, 1,
+                               cfl_diff, c->partials, tx, tiles);
+            hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials, nb, 2, c->scal);
+            CFD_HIP(hipGetLastError());
+            CFD_HIP(hipMemcpyAsync(c->scal + DT_AHEAD_OFF + 1, c->scal + 1, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
         CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF, 2, 1));
         return read_scalars(c, DT_AHEAD_OFF, 2, out);
     }
@@ -876,18 +886,25 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         MomArgs ma{c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j, c->bu, c->bv};
         // cont != nullptr: the pass that closes an inner iteration -- in laminar runs it also evaluates the time-step
         // minima the next outer step will ask for (same fields; parameters of the last cfd_compute_dt call)
-        const bool dt_too = cont && !c->turbulent && c->dt_lookahead && c->dtp_set;
-        if (c->turbulent) {
-            hipLaunchKernelGGL((k_flux_march<2, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
-                               (double *)nullptr, c->partials);
-        } else if (dt_too) {
-            ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl; ma.use_diff = c->dtp_use_diff;
-            hipLaunchKernelGGL((k_flux_march<2, false, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
-                               (double *)nullptr, c->partials);
+        const bool dt_too = cont && c->dt_lookahead && c->dtp_set && (c->dtp_use_cfl || !c->turbulent);
+        if (dt_too) {
+            // turbulent runs: nu_t changes before the next step, only the advective minimum can be taken ahead
+            ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
+            ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
+            if (c->turbulent)
+                hipLaunchKernelGGL((k_flux_march<2, true, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
+                                   (double *)nullptr, c->partials);
+            else
+                hipLaunchKernelGGL((k_flux_march<2, false, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
+                                   (double *)nullptr, c->partials);
             hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials + MAX_PARTIALS, fm.blocks, 2,
                                c->scal + DT_AHEAD_OFF);
             c->dt_ahead = true;
+            c->dt_ahead_diff = !c->turbulent;
             c->dt_ahead_cur = c->cur;
+        } else if (c->turbulent) {
+            hipLaunchKernelGGL((k_flux_march<2, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
+                               (double *)nullptr, c->partials);
         } else {
             hipLaunchKernelGGL((k_flux_march<2, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
                                (double *)nullptr, c->partials);

@@ -545,10 +545,12 @@ def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path, monkeypat
 
 
 @pytest.mark.parametrize("name,schedule", [("channel_forced_24", None), ("inlet_outlet_channel", None),
-                                           ("channel_forced_24", [(0.2, 0), (0.6, 3)])])
+                                           ("channel_forced_24", [(0.2, 0), (0.6, 3)]),
+                                           # k-omega: only the advective minimum is taken ahead (nu_t changes in between)
+                                           ("channel_forced_komega_24", None), ("half_cylinder_komega", None)])
 def test_time_step_minima_computed_ahead(name, schedule, tmp_path, monkeypatch):
-    """Laminar runs: the pass that closes an inner iteration also evaluates the CFL / diffusive minima of the next
-    outer step (same fields).  Times, fields and logs keep the bits of the separate time-step kernel; with a CFL
+    """The pass that closes an inner iteration also evaluates the CFL / diffusive minima of the next outer step
+    (same fields; in turbulent runs the advective one only).  Times, fields and logs keep the bits of the separate time-step kernel; with a CFL
     schedule the parameters differ from step to step and the values computed ahead must be discarded."""
     from cfd_amd import mesh as hip_mesh
     from cfd_amd import solver as hip_solver
