@@ -23,6 +23,7 @@ ALGO = {"k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 64, "k_mg_up<true>
         "k_flux_march<0, false, false>": 104, "k_flux_march<1, false, false>": 112, "k_flux_march<2, false, false>": 120,
         "k_flux_march<2, false, true>": 128, "k_flux_march<3, false, false>": 88, "k_flux_march<2, true, false>": 128,
         "k_flux_march<4, false, false>": 144,
+        "k_flux_march<2, true, true>": 128, "k_dt": 16,
         "k_mg_down_k<true, 3, false>": 34, "k_mg_down_k<true, 3, true>": 50,
         # k-omega variant
         "k_flux_march<2, true>": 128, "k_turb_rhs": 144, "k_flux_march<4, false>": 144, "k_komega_coeffs<true>": 136, "k_komega_coeffs<false>": 112, "k_clip": 16,
