@@ -604,6 +604,33 @@ def test_residual_update_inside_the_presmoother(name, tmp_path, monkeypatch):
     assert np.array_equal(out["0"][2], out["1"][2])
 
 
+@pytest.mark.parametrize("turbulent", [False, True])
+def test_all_fusions_together_keep_the_bits_over_many_steps(turbulent, monkeypatch):
+    """The bench workload at 512^2 for 40 outer steps: eddy viscosity inside the conductance pass, time-step minima and
+    momentum right-hand sides taken ahead, PCG residual update inside the pre-smoother -- all on vs all off gives the
+    same u, v, p, k, omega, nu_t bit for bit and the same time."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for mode in ("0", "1"):
+        for var in ("CFD_FUSE_NUT", "CFD_DT_LOOKAHEAD", "CFD_FUSE_RESID", "CFD_RHS_LOOKAHEAD"):
+            monkeypatch.setenv(var, mode)
+        dev, ctl, cfg = bench.setup_device(512, turbulent, 2, 1e-8, 0)
+        t = 0.0
+        for step in range(40):
+            info = advance_one_step(dev, ctl, step)
+            t += info["dt"]
+        ids = [L.F_U, L.F_V, L.F_P, L.F_NUT] + ([L.F_K, L.F_OMEGA] if turbulent else [])
+        out[mode] = (t, [dev.download(f) for f in ids], dev.stats())
+        dev.close()
+    assert out["0"][0] == out["1"][0] and out["0"][0] > 0.0
+    for a, b in zip(out["0"][1], out["1"][1]):
+        assert np.array_equal(a, b)
+    assert np.all(np.isfinite(out["1"][1][0])) and np.abs(out["1"][1][0]).max() > 0.5
+    assert out["0"][2]["p_iters"] == out["1"][2]["p_iters"] and out["0"][2]["mom_iters"] == out["1"][2]["mom_iters"]
+
+
 def test_committed_reference_sst_run(tmp_path):
     """Tier A for the SST closure: the reference's own committed 5x20 SST run (real pyamg, rtol 1e-8):
     first logged steps of the residual / friction logs and states/sst/fields_000000.npz with its caches."""
