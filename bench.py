@@ -9,12 +9,14 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
     torchrun ... bench.py --gpus N ...                        (one rank per GPU)
 
 The JSON line also carries
-  roofline     : the kernel with the largest share of device time, k_chebk<2,4> (momentum solve: four fused
-                 Jacobi-Chebyshev iterations of u and v per launch; 14-15 % in profiles/r1o_*), timed live with
-                 HIP-event pairs around every launch inside the timed steps; achieved = 104 B/cell * Ni*Nj /
-                 avg duration (x_k, x_k-1, b of both right-hand sides, D, c_i, c_j read; two iterates of each
-                 written).  --probe 0 / 7 / 1 / 2 / 9 select the PCG direction step k_cg_pq (14.6-14.9 %), the
-                 multigrid up / down kernels, the momentum RHS kernel or the single-RHS Chebyshev kernel.
+  roofline     : the kernel with the largest share of device time, k_cg_pq (the MG-PCG direction step: p update,
+                 SpMV, (p,q) and the deferred x update in one marching pass; 15.3 % in profiles/r1o_*, just ahead of
+                 the momentum Chebyshev kernel k_chebk<2,4> with 14.8 %), timed live with HIP-event pairs around
+                 every launch inside the timed steps; achieved = 64 B/cell * Ni*Nj / avg duration (z, p_old, c_i,
+                 c_j, x read; p, q, x written; the diagonal is recomputed from the face planes).  --probe 8 / 9 / 7 /
+                 1 / 10 / 2 select the Chebyshev kernels (two / one right-hand side), the multigrid up / down / down
+                 with residual update kernels or the momentum RHS kernel; all of them are also reported once per run
+                 in roofline_other_kernels.
                  traffic = HBM bytes per launch from the committed PMC passes of this command
                  (profiles/r1o_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
                  were measured on.
@@ -123,7 +125,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--probe", type=int, default=8, help="kernel id for the live roofline probe (8 = momentum Chebyshev, "
+    ap.add_argument("--probe", type=int, default=0, help="kernel id for the live roofline probe (8 = momentum Chebyshev, "
                     "0 = PCG direction step, 7 / 1 / 10 = multigrid up / down / down with residual update, 2 = momentum RHS, "
                     "9 = single-RHS Chebyshev)")
     ap.add_argument("--mg-sweeps", type=int, default=None, help="pre = post smoothing sweeps (2 or 3)")
