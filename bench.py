@@ -10,7 +10,7 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
 
 The JSON line also carries
   roofline     : the kernel with the largest share of device time, k_cg_pq (the MG-PCG direction step: p update,
-                 SpMV, (p,q) and the deferred x update in one marching pass; 15.3 % in profiles/r1o_*, just ahead of
+                 SpMV, (p,q) and the deferred x update in one marching pass; 15.3 % in profiles/r1p_*, just ahead of
                  the momentum Chebyshev kernel k_chebk<2,4> with 14.8 %), timed live with HIP-event pairs around
                  every launch inside the timed steps; achieved = 64 B/cell * Ni*Nj / avg duration (z, p_old, c_i,
                  c_j, x read; p, q, x written; the diagonal is recomputed from the face planes).  --probe 8 / 9 / 7 /
@@ -18,7 +18,7 @@ The JSON line also carries
                  with residual update kernels or the momentum RHS kernel; all of them are also reported once per run
                  in roofline_other_kernels.
                  traffic = HBM bytes per launch from the committed PMC passes of this command
-                 (profiles/r1o_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
+                 (profiles/r1p_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
                  were measured on.
   strong_scaling_leg (N > 1): after the timed region the same --size x --size channel is split over the N GPUs and
                  timed the same way; its value / the 1-GPU value is the strong-scaling speed-up.  The headline stays
@@ -43,7 +43,7 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
-# 8192^2 (profiles/r1o_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
+# 8192^2 (profiles/r1p_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
 PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.32, 9: 70.53, 7: 41.65, 1: 33.87, 10: 49.93, 2: 126.08}
 
 
