@@ -113,6 +113,42 @@ def cpu_baseline(n_cpu, steps, max_iter):
                       f"numpy/SuperLU single-threaded; total {time.perf_counter() - t0:.1f} s"}
 
 
+def strong_scaling_leg(args, n, world, local, barrier, torch, dist):
+    """N > 1, after the timed region: the same n x n channel split over the N GPUs, timed like the headline.  Any
+    (collective, hence symmetric) failure is reported in the JSON line instead of costing the headline."""
+    from cfd_amd.solver import advance_one_step
+    try:
+        sdev, sctl, _ = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1, args.transport)
+        sstep = 0
+        for _ in range(args.warmup):
+            advance_one_step(sdev, sctl, sstep)
+            sstep += 1
+        sdev.synchronize()
+        s0 = sdev.comm_counts()
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            advance_one_step(sdev, sctl, sstep)
+            sstep += 1
+        sdev.synchronize()
+        barrier()
+        s_elapsed = time.perf_counter() - ts
+        t = torch.tensor([s_elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s_elapsed = float(t.item())
+        sst = sdev.stats()
+        strong_leg = {"workload": f"the {n}x{n} channel as {world} j-slabs of {n}x{n // world} cells",
+                      "ms_per_step": 1e3 * s_elapsed / args.steps, "value": n * n / (s_elapsed / args.steps),
+                      "unit": "cell-updates/s", "steps": args.steps, "warmup": args.warmup,
+                      "pressure_iters_last_step": sst["p_iters"], "momentum_iters_last_step": sst["mom_iters"],
+                      "collectives_per_step": dict(zip(("halo_exchanges", "all_reduces", "all_gathers"),
+                                                       [(a - b) / args.steps for a, b in zip(sdev.comm_counts(), s0)]))}
+        sdev.close()
+        return strong_leg
+    except Exception as exc:      # noqa: BLE001 - reported, not fatal
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,32 +275,7 @@ def main():
     # max over ranks.  Reported beside the headline as "strong_scaling_leg"; value(N) / value(1 GPU) is its speed-up.
     strong_leg = None
     if world > 1 and not args.strong and not args.no_strong_leg and n % world == 0 and (n // world) % 2 == 0 and n // world >= 4:
-        sdev, sctl, _ = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1, args.transport)
-        sstep = 0
-        for _ in range(args.warmup):
-            advance_one_step(sdev, sctl, sstep)
-            sstep += 1
-        sdev.synchronize()
-        s0 = sdev.comm_counts()
-        barrier()
-        ts = time.perf_counter()
-        for _ in range(args.steps):
-            advance_one_step(sdev, sctl, sstep)
-            sstep += 1
-        sdev.synchronize()
-        barrier()
-        s_elapsed = time.perf_counter() - ts
-        t = torch.tensor([s_elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        s_elapsed = float(t.item())
-        sst = sdev.stats()
-        strong_leg = {"workload": f"the {n}x{n} channel as {world} j-slabs of {n}x{n // world} cells",
-                      "ms_per_step": 1e3 * s_elapsed / args.steps, "value": n * n / (s_elapsed / args.steps),
-                      "unit": "cell-updates/s", "steps": args.steps, "warmup": args.warmup,
-                      "pressure_iters_last_step": sst["p_iters"], "momentum_iters_last_step": sst["mom_iters"],
-                      "collectives_per_step": dict(zip(("halo_exchanges", "all_reduces", "all_gathers"),
-                                                       [(a - b) / args.steps for a, b in zip(sdev.comm_counts(), s0)]))}
-        sdev.close()
+        strong_leg = strong_scaling_leg(args, n, world, local, barrier, torch, dist)
     copy_gbs = None
     if rank == 0:
         a = torch.empty(n * n, dtype=torch.float64, device="cuda")
