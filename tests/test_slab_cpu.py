@@ -174,3 +174,36 @@ def test_slab_collectives_gloo(world):
             p.kill()
     bad = [r for r in results if r[1] != "ok"]
     assert not bad, "\n".join(f"rank {r}: {msg}" for r, msg in bad)
+
+
+def test_rehearsal_env_gives_every_rank_a_host_of_its_own(monkeypatch):
+    """One-GPU rehearsal of the RCCL transports: distinct NCCL_HOSTID per rank, loopback sockets, user settings kept."""
+    import os
+    from cfd_amd.slab import rehearsal_env
+    monkeypatch.delenv("NCCL_HOSTID", raising=False)
+    monkeypatch.delenv("NCCL_SOCKET_IFNAME", raising=False)
+    monkeypatch.setenv("NCCL_IB_DISABLE", "0")
+    ids = set()
+    for rank in range(4):
+        rehearsal_env(rank)
+        ids.add(os.environ["NCCL_HOSTID"])
+    assert len(ids) == 4
+    assert os.environ["NCCL_SOCKET_IFNAME"] == "lo" and os.environ["NCCL_IB_DISABLE"] == "0"
+
+
+def test_foreign_plane_describes_raw_device_doubles():
+    """Planes the library allocated itself (SST caches) reach torch through __cuda_array_interface__ (no copy)."""
+    from cfd_amd.slab import _ForeignPlane
+    cai = _ForeignPlane(0x7F0000001000, 1234).__cuda_array_interface__
+    assert cai["shape"] == (1234,) and cai["typestr"] == "<f8" and cai["data"] == (0x7F0000001000, False) and cai["version"] == 2
+
+
+def test_abi_declares_the_rccl_transport():
+    """The native transport entry points are part of the C ABI (and of the loaded library)."""
+    from pathlib import Path
+    header = (Path(__file__).resolve().parents[1] / "include" / "cfd_hip.h").read_text()
+    for name in ("cfd_rccl_unique_id", "cfd_set_comm_rccl", "cfd_comm_counts", "cfd_comm_counts_by_phase"):
+        assert f"int {name}(" in header
+    assert "#define CFD_RCCL_ID_BYTES 128" in header
+    from cfd_amd import _lib
+    assert _lib.RCCL_ID_BYTES == 128
