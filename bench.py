@@ -47,7 +47,7 @@ SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read 
 PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.32, 9: 70.53, 7: 41.65, 1: 33.87, 10: 49.93, 2: 126.08}
 
 
-def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None):
+def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, tuning=None, lookahead=True):
     """One n x n slab per GPU of an n x (n * world) channel of height `world` (same cells, same cell
     size on every rank: weak scaling); world = 1 is the single-GPU workload of SURVEY.md 8(d).
     --strong calls this with world = 1 under an initialised process group: the n x n channel itself is
@@ -60,6 +60,10 @@ def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None):
     from cfd_amd.workloads import channel_forced_config, perturbed_parabola_rows
 
     cfg, mp = channel_forced_config(n, turbulent, max_iter, tol, nj=n * world, length_j=float(world))
+    if tuning:
+        cfg["solver"]["tuning"] = dict(tuning)
+    if not lookahead:
+        cfg["solver"]["flux_kernels"] = {"marching": True, "lookahead": False}
     x, y = rect_node_axes(**mp)
     dev = slab_device(n, n * world, device, transport=transport)
     dev.mesh_from_rect(x, y)

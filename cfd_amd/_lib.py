@@ -38,7 +38,7 @@ class TurbOp(C.Structure):
 class SolveStats(C.Structure):
     _fields_ = [("mom_iters", C.c_int32), ("p_iters", C.c_int32), ("k_iters", C.c_int32),
                 ("p_solver", C.c_int32), ("mom_solver", C.c_int32), ("k_solver", C.c_int32), ("mom_relres", C.c_double * 2), ("p_relres", C.c_double),
-                ("k_relres", C.c_double * 2)]
+                ("k_relres", C.c_double * 2), ("p_unconverged", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HipError(RuntimeError):
@@ -110,7 +110,9 @@ SIGNATURES = {
     "cfd_pressure_krylov": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_int, C.POINTER(C.c_int), _dp]),
     "cfd_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "cfd_probe": (C.c_int, [_vp, C.c_int]),
-    "cfd_probe_read": (C.c_int, [_vp, C.POINTER(C.c_int), _dp]),
+    "cfd_probe_read": (C.c_int, [_vp, C.POINTER(C.c_int), _dp, _dp]),
+    "cfd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "cfd_kernel_counts": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.c_int, C.c_int]),
     "cfd_phase_times": (C.c_int, [_vp, _dp, C.c_int]),
     "cfd_enable_phase_timing": (C.c_int, [_vp, C.c_int]),
 }

@@ -578,12 +578,32 @@ int cfd_set_transport_solver(cfd_ctx *ctx, int warm_start, int chebyshev, double
     if (!(rho_max > 0.0 && rho_max < 1.0) || max_iters < 1) { set_error("cfd_set_transport_solver: bad parameters"); return CFD_E_ARG; }
     c->warm_start = warm_start ? 1 : 0; c->use_chebyshev = chebyshev ? 1 : 0;
     c->cheb_rho_max = rho_max; c->cheb_max_iters = max_iters;
-    if (const char *e = getenv("CFD_CHEB_STAGES")) c->cheb_stages = atoi(e);      // tuning / A-B measurements
-    if (const char *e = getenv("CFD_MARCH_FLUX")) c->march_flux = atoi(e);
-    if (const char *e = getenv("CFD_FUSE_NUT")) c->fuse_nut = atoi(e);
-    if (const char *e = getenv("CFD_DT_LOOKAHEAD")) c->dt_lookahead = atoi(e);
-    if (const char *e = getenv("CFD_FUSE_RESID")) c->fuse_resid = atoi(e);
-    if (const char *e = getenv("CFD_RHS_LOOKAHEAD")) c->rhs_lookahead = atoi(e);
+    return CFD_OK;
+}
+
+// Tuning / A-B switches of the kernel forms (tests and measurements; the product path never reads the environment).
+int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
+    CTX_MUT(ctx);
+    if (!name) { set_error("cfd_set_option: null name"); return CFD_E_ARG; }
+    const std::string n(name);
+    const int iv = (int)value;
+    if (n == "cheb_stages") { if (iv != 1 && iv != 2 && iv != 4) { set_error("cheb_stages: 1, 2 or 4"); return CFD_E_ARG; } c->cheb_stages = iv; }
+    else if (n == "cheb_prefetch") { if (iv != 1 && iv != 2) { set_error("cheb_prefetch: 1 or 2"); return CFD_E_ARG; } c->cheb_prefetch = iv; }
+    else if (n == "fuse_nut") c->fuse_nut = iv ? 1 : 0;
+    else if (n == "dt_lookahead") c->dt_lookahead = iv ? 1 : 0;
+    else if (n == "fuse_resid") c->fuse_resid = iv ? 1 : 0;
+    else if (n == "nt_stores") c->nt_stores = iv < 0 ? -1 : (iv ? 1 : 0);
+    else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
+    else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
+    else { set_error("cfd_set_option: unknown option '%s'", name); return CFD_E_ARG; }
+    return CFD_OK;
+}
+
+int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset) {
+    CTX(ctx);
+    if (!counts || n < 1) { set_error("cfd_kernel_counts: bad arguments"); return CFD_E_ARG; }
+    for (int q = 0; q < n; ++q) counts[q] = q < KC_COUNT ? c->kc[q] : 0;
+    if (reset) for (int q = 0; q < KC_COUNT; ++q) c->kc[q] = 0;
     return CFD_OK;
 }
 
@@ -787,7 +807,7 @@ static int do_predictor(Ctx *c, double dt, double res[3]) {
         if (!have) {
             c->probe_begin(2);
             CFD_TRY(launch_momentum_rhs(c, dt, c->U(), c->V(), c->P()));
-            c->probe_end(2);
+            c->probe_end(2, c->last_rhs_bytes);
         }
     }
     {
@@ -818,7 +838,7 @@ static int finish_iteration(Ctx *c, double dt, double *cont) {
     if (!c->march_flux || !c->rhs_lookahead) return launch_continuity(c, c->U(), c->V(), c->P(), cont);
     c->probe_begin(2);
     CFD_TRY(launch_momentum_rhs(c, dt, c->U(), c->V(), c->P(), cont));
-    c->probe_end(2);
+    c->probe_end(2, c->last_rhs_bytes);
     c->rhs_ahead = true;
     c->rhs_dt = dt;
     c->rhs_cur = c->cur;
@@ -1237,12 +1257,14 @@ int cfd_probe(cfd_ctx *ctx, int kernel) {
     }
     c->probe_kernel = kernel;
     c->probe_n = 0;
+    c->probe_bytes = 0.0;
     return CFD_OK;
 }
 
-int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us) {
+int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us, double *avg_bytes_per_cell) {
     CTX(ctx);
     if (!count || !avg_us) return CFD_E_ARG;
+    if (avg_bytes_per_cell) *avg_bytes_per_cell = c->probe_n ? c->probe_bytes / c->probe_n : 0.0;
     CFD_HIP(hipStreamSynchronize(c->stream));
     double tot = 0.0;
     for (int q = 0; q < c->probe_n; ++q) {

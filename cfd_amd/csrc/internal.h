@@ -1,8 +1,9 @@
 // Internal declarations shared by the HIP translation units of libcfd_hip.so.
-// gfx950 only.  Device layout: planes [jg][ig], ig contiguous; element (ig, jg) of a
-// ghosted (Ni+2) x (Nj+2) plane lives at (jg + 1) * pitch + ig + 1 (one spare row on each
-// side, see Geo) so that interior cell i = 0 (ig = 1) is 16-byte aligned.  Face planes share the geometry: i-face f (west
-// face of cell f) sits at the index of cell f, j-face g (south face) at cell g.
+// gfx950 only.  Device layout: planes [row][col], col contiguous, NG = CFD_GHOST_ROWS ghost rows below and
+// above the interior rows and two spare columns on the left: interior cell (i, j) lives at
+// (j + NG) * pitch + i + 2 (Geo::cell), so that cell i = 0 is 16-byte aligned; element (ig, jg) of the
+// reference's ghosted (Ni+2) x (Nj+2) array is Geo::at(ig, jg) = cell(ig - 1, jg - 1).  Face planes share
+// the geometry: i-face f (west face of cell f) sits at the index of cell f, j-face g (south face) at cell g.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,9 +37,8 @@ struct Geo {
     int cutlo, cuthi;
     __host__ __device__ inline bool blo(int j) const { return j == 0 && !cutlo; }          // physical low-j boundary row
     __host__ __device__ inline bool bhi(int j) const { return j == nj - 1 && !cuthi; }     // physical high-j boundary row
-    // two ghost rows below and above the interior (rows -2, -1 and nj, nj+1): the inner pair is the
-    // reference's ghost layer, the outer pair is the extra halo row of the two-sweep fused kernels
-    // and of the j-slab exchange.  ghosted index jg = j + 1.
+    // NG ghost rows below and above the interior: the innermost one is the reference's ghost layer, the
+    // others are halo rows of the fused kernels / of the j-slab exchange.  ghosted index jg = j + 1.
     __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)(jg + NG - 1) * pitch + ig + 1; }
     __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + NG) * pitch + i + 2; }
     __host__ inline size_t plane_elems() const { return (size_t)(nj + 2 * NG) * pitch; }
@@ -105,6 +105,21 @@ __device__ __forceinline__ double lane_right(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+
+// Streaming store: planes larger than the 256 MiB Infinity Cache are written once and read back only after
+// everything else has passed through the cache, so their stores carry the nontemporal hint (tools/stream_probe2.hip:
+// +5-8 % on the marching access pattern with plain loads; nontemporal LOADS lose, they bypass the L1 reuse of
+// neighbouring lanes / rows).  `nt` is wave-uniform (a kernel argument).
+__device__ __forceinline__ void store_stream(double *p, double v, int nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
+enum {
+    KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_COUNT = 16
+};
 
 // ------------------------------------------------------------------ multigrid level
 struct Level {
@@ -209,7 +224,7 @@ struct Ctx {
     // Jacobi damping of the smoothing sweeps, used cyclically (sweep s takes mg_om[s % mg_nom]); the sweeps of
     // a pass commute, so the preconditioner is symmetric for any list.  Single-rank default: V(3,3) with
     // (1.0, 0.55, 0.9) -- 5 PCG iterations per solve at 8192^2; (1.0, 0.6) with V(2,2) needs 7, (0.8, 0.8) 7.5.
-    // j-slab contexts keep V(2,2) (a cut carries two halo rows).
+    // j-slab contexts run the same kernels (a cut carries NG = 4 halo rows).
     double mg_om[4] = {1.0, 0.55, 0.9, 0.0};
     int mg_nom = 3;
     inline double om_at(int s) const { return mg_om[s % mg_nom]; }
@@ -217,10 +232,19 @@ struct Ctx {
     int warm_start = 1;          // Krylov initial guess = previous field (reference: zero)
     int use_chebyshev = 1;       // Chebyshev semi-iteration for time-step dominated transport systems
     double cheb_rho_max = 0.95;  // ... i.e. Jacobi row-sum bound below this
-    int cheb_stages = 4;         // Chebyshev iterations fused per launch on single-slab contexts (2 or 4)
+    int cheb_stages = 4;         // Chebyshev iterations fused per launch (2 or 4)
+    int cheb_prefetch = 2;       // rows of loads a k_chebk wave keeps in flight (1 or 2)
+    int nt_stores = -1;          // nontemporal stores in the streaming kernels: -1 = when a plane exceeds the Infinity Cache
+    int march_ls = 0;            // rows per segment of the K >= 3 marching kernels (0 = default)
+    long long kc[KC_COUNT] = {};  // launches per kernel family (cfd_kernel_counts)
+    inline int nts(const Geo &geo) const {
+        return nt_stores >= 0 ? nt_stores : (geo.plane_elems() * sizeof(double) > ((size_t)256 << 20) ? 1 : 0);
+    }
+    inline int nts() const { return nts(g); }
     int cheb_max_iters = 80;     // ... and predicted iteration count below this; else BiCGStab
     int stats_last_solver = 0;   // 1 = the last transport solve was Chebyshev
     int mg_fused = 1;            // fused marching V-cycle kernels where applicable
+    int mg_line = -1;            // j-line (tridiagonal) Jacobi smoother: -1 = on levels whose c_j / c_i anisotropy asks for it
     // time-step minima of the next outer step evaluated by the pass that closes an inner iteration (laminar runs)
     int dt_lookahead = 1;
     bool dt_ahead = false, dt_ahead_diff = false, dtp_set = false;
@@ -262,11 +286,17 @@ struct Ctx {
     int probe_kernel = -1;
     std::vector<hipEvent_t> probe_e0, probe_e1;
     int probe_n = 0;
+    double probe_bytes = 0.0;     // algorithmic bytes per cell summed over the timed launches (they differ per launch)
+    double last_rhs_bytes = 0.0;  // algorithmic bytes per cell of the last momentum right-hand side launch
     inline void probe_begin(int id) {
         if (id == probe_kernel && probe_n < (int)probe_e0.size()) (void)hipEventRecord(probe_e0[probe_n], stream);
     }
-    inline void probe_end(int id) {
-        if (id == probe_kernel && probe_n < (int)probe_e0.size()) { (void)hipEventRecord(probe_e1[probe_n], stream); ++probe_n; }
+    inline void probe_end(int id, double bytes_per_cell = 0.0) {
+        if (id == probe_kernel && probe_n < (int)probe_e0.size()) {
+            (void)hipEventRecord(probe_e1[probe_n], stream);
+            ++probe_n;
+            probe_bytes += bytes_per_cell;
+        }
     }
 
     MeshDev mesh() const {

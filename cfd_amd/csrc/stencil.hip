@@ -501,6 +501,7 @@ struct MomArgs {
     const double *nut, *omega;
     double nu, cfl, cfl_diff;
     int use_cfl, use_diff;
+    int nts;                       // nontemporal stores of the right-hand side planes (store_stream)
 };
 
 template <int MODE, bool KG, bool DT = false>
@@ -649,8 +650,8 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                         if (g.blo(jo)) { const double a = ma.aj[c]; b_u += a * u2; b_v += a * v2; }
                         if (g.bhi(jo)) { const double a = ma.aj[c + P]; b_u += a * cur.u; b_v += a * cur.v; }
                     }
-                    ma.bu[c] = b_u;
-                    ma.bv[c] = b_v;
+                    store_stream(ma.bu + c, b_u, ma.nts);
+                    store_stream(ma.bv + c, b_v, ma.nts);
                     const double div = (fe - fw + fn - fs) / vol;
                     acc += div * div;
                     if (DT) {
@@ -726,8 +727,8 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                         if (g.blo(jo)) { const double a = ma.aj[c]; b_k += a * k2; b_w += a * w2; }
                         if (g.bhi(jo)) { const double a = ma.aj[c + P]; b_k += a * cur.k; b_w += a * cur.w; }
                     }
-                    ma.bu[c] = b_k;
-                    ma.bv[c] = b_w;
+                    store_stream(ma.bu + c, b_k, ma.nts);
+                    store_stream(ma.bv + c, b_w, ma.nts);
                 }
                 u2 = prv.u; v2 = prv.v; k2 = prv.k; w2 = prv.w;
             } else if (MODE == 3) {
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
                 const double vol = prv.vol;
                 const double div = (fe_p - fw_p + fs_c - fs_p) / vol;
                 if (MODE == 0) acc += div * div;
-                else { const double bv = vol * (-div); bout[(size_t)(jo + NG) * P + colo] = bv; acc += bv; }   // sum b (nullspace form)
+                else { const double bv = vol * (-div); store_stream(bout + (size_t)(jo + NG) * P + colo, bv, ma.nts); acc += bv; }   // sum b (nullspace form)
             }
             fw_p = fw_c; fs_p = fs_c;
             lw_p = lw_c; ls_p = ls_c;
@@ -884,9 +885,15 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         // marching kernel: the continuity sum of the same fluxes comes for free (cont != nullptr reads it)
         const FluxMarch fm = flux_march_geo(c->g);
         MomArgs ma{c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j, c->bu, c->bv};
+        ma.nts = c->nts();
+        c->kc[KC_FLUX_MARCH] += 1;
+        if (fm.nstrips > 1) c->kc[KC_FLUX_MARCH_MULTISTRIP] += 1;
         // cont != nullptr: the pass that closes an inner iteration -- in laminar runs it also evaluates the time-step
         // minima the next outer step will ask for (same fields; parameters of the last cfd_compute_dt call)
         const bool dt_too = cont && c->dt_lookahead && c->dtp_set && (c->dtp_use_cfl || !c->turbulent);
+        // 13 planes read (u, v, p, a_P, V, w x 2, n x 4, S x 2), b_u, b_v written; + k in turbulent runs; + lmin for the
+        // diffusive minimum taken ahead
+        c->last_rhs_bytes = 120.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0);
         if (dt_too) {
             // turbulent runs: nu_t changes before the next step, only the advective minimum can be taken ahead
             ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
@@ -913,6 +920,7 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         if (cont) return finish_continuity(c, fm.blocks, cont);
         return CFD_OK;
     }
+    c->kc[KC_FLUX_TILE] += 1;
     hipLaunchKernelGGL(k_momentum_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f,
                        c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j,
                        c->bu, c->bv);
@@ -964,6 +972,7 @@ int launch_turb_rhs(Ctx *c, double dt) {
     if (c->march_flux) {
         const FluxMarch fm = flux_march_geo(c->g);
         MomArgs ma{c->k, c->ti, c->tj, 1.0 / dt, 0.0, 0.0, c->per_i, c->per_j, c->bu, c->bv};
+        ma.nts = c->nts();
         ma.nut = c->nut; ma.omega = c->omega;
         hipLaunchKernelGGL((k_flux_march<4, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
                            (double *)nullptr, c->partials);
@@ -1028,7 +1037,11 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
     if (c->march_flux) {
         const FluxMarch fm = flux_march_geo(c->g);
-        hipLaunchKernelGGL((k_flux_march<1, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, MomArgs{}, b,
+        MomArgs ma{};
+        ma.nts = c->nts();
+        c->kc[KC_FLUX_MARCH] += 1;
+        if (fm.nstrips > 1) c->kc[KC_FLUX_MARCH_MULTISTRIP] += 1;
+        hipLaunchKernelGGL((k_flux_march<1, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma, b,
                            c->partials);
     } else {
         hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
@@ -1190,7 +1203,7 @@ int launch_pcorr_bc(Ctx *c) {
 // ----------------------------------------------------------------------------------
 __global__ void k_correct(Geo g, MeshDev m, const double *pc, const double *ap, const double *us, const double *vs,
                           const double *u0, const double *v0, const double *p0, double *uo, double *vo, double *po,
-                          double ru, double rv, double rp) {
+                          double ru, double rv, double rp, int nts) {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
     if (i >= g.ni || j >= g.nj) return;
     const size_t c = g.cell(i, j);
@@ -1199,15 +1212,15 @@ __global__ void k_correct(Geo g, MeshDev m, const double *pc, const double *ap, 
     const double d = m.vol[c] / ap[c];
     const double uc = us[c] - d * gx, vc = vs[c] - d * gy;
     const double a = u0[c], b = v0[c];
-    uo[c] = a + ru * (uc - a);
-    vo[c] = b + rv * (vc - b);
-    po[c] = p0[c] + rp * pc[c];
+    store_stream(uo + c, a + ru * (uc - a), nts);
+    store_stream(vo + c, b + rv * (vc - b), nts);
+    store_stream(po + c, p0[c] + rp * pc[c], nts);
 }
 
 int launch_correct(Ctx *c, const double *us, const double *vs, const double *u0, const double *v0, const double *p0,
                    double *uo, double *vo, double *po, double ru, double rv, double rp) {
     hipLaunchKernelGGL(k_correct, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->pcorr, c->ap,
-                       us, vs, u0, v0, p0, uo, vo, po, ru, rv, rp);
+                       us, vs, u0, v0, p0, uo, vo, po, ru, rv, rp, c->nts());
     CFD_HIP(hipGetLastError());
     return CFD_OK;
 }

@@ -288,7 +288,8 @@ class Device:
                 "p_solver": "mg-pcg" if s.p_solver == 0 else "mg-bicgstab",
                 "mom_solver": "chebyshev" if s.mom_solver == 1 else "bicgstab",
                 "k_solver": "chebyshev" if s.k_solver == 1 else "bicgstab",
-                "mom_relres": tuple(s.mom_relres), "p_relres": s.p_relres, "k_relres": tuple(s.k_relres)}
+                "mom_relres": tuple(s.mom_relres), "p_relres": s.p_relres, "k_relres": tuple(s.k_relres),
+                "p_unconverged": s.p_unconverged}
 
     def bulk_velocity(self, field_id=_lib.F_U):
         out = C.c_double()
@@ -376,10 +377,25 @@ class Device:
     def probe(self, kernel):
         check(self.lib.cfd_probe(self._h, int(kernel)))
 
-    def probe_read(self):
-        n, us = C.c_int(), C.c_double()
-        check(self.lib.cfd_probe_read(self._h, C.byref(n), C.byref(us)))
-        return n.value, us.value
+    def probe_read(self, with_bytes=False):
+        """(launches timed, mean duration in us[, mean algorithmic bytes per cell of those launches])."""
+        n, us, bpc = C.c_int(), C.c_double(), C.c_double()
+        check(self.lib.cfd_probe_read(self._h, C.byref(n), C.byref(us), C.byref(bpc)))
+        return (n.value, us.value, bpc.value) if with_bytes else (n.value, us.value)
+
+    def set_option(self, name, value):
+        """Tuning / A-B switch of a kernel form (include/cfd_hip.h: cfd_set_option)."""
+        check(self.lib.cfd_set_option(self._h, str(name).encode(), float(value)))
+
+    KERNEL_COUNT_NAMES = ("cheb4_2rhs", "cheb4_1rhs", "cheb2", "cheb1", "bicgstab_iters", "flux_march",
+                          "flux_march_multistrip", "flux_tile", "mg_fused_levels_max", "mg_deferred_resid", "cg_pq",
+                          "vcycles", "mg_line_levels_max")
+
+    def kernel_counts(self, reset=False):
+        """Launches per kernel family since the last reset (include/cfd_hip.h: cfd_kernel_counts)."""
+        out = (C.c_longlong * 16)()
+        check(self.lib.cfd_kernel_counts(self._h, out, 16, int(reset)))
+        return dict(zip(self.KERNEL_COUNT_NAMES, [int(v) for v in out]))
 
     def enable_phase_timing(self, on=True):
         check(self.lib.cfd_enable_phase_timing(self._h, int(on)))

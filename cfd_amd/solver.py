@@ -275,6 +275,8 @@ def configure_device(dev, config, geometry, nu, turb_on):
     dev.set_pressure_nullspace(pressure_cfg.get("nullspace", True))
     fk = solver_cfg.get("flux_kernels", {})
     dev.set_flux_kernels(fk.get("marching", True), fk.get("lookahead", True))
+    for name, value in solver_cfg.get("tuning", {}).items():       # A-B switches of the kernel forms (tests, measurements)
+        dev.set_option(name, value)
     params = config.get("turbulence", {}).get("params", {})
     dev.set_turbulence_clip(params.get("k_min", 1.0e-10), params.get("omega_min", 1.0e-10))
     tables = BoundaryTables(config["boundary"], dev.ni, dev.nj_global, geometry, nu, turb_on)
@@ -376,6 +378,11 @@ def advance_one_step(dev, ctl, step):
     return {"dt": dt, "dt_adv": dt_adv, "dt_diff": dt_diff, "inner": inner, "cont": cont,
             "mom_u": mom_u, "mom_v": mom_v, "step_cfl": step_cfl, "step_cfl_diff": step_cfl_diff,
             "step_dt_max": step_dt_max}
+
+
+# what the last run_case call went through (tests assert on it): launches per kernel family, multigrid levels,
+# solver statistics of the last step
+LAST_RUN = {}
 
 
 # ------------------------------------------------------------------ run_case
@@ -533,6 +540,14 @@ def run_case(config):
             step += 1
 
         dev.download_fields(fields)
+        stats = dev.stats()
+        LAST_RUN.clear()
+        LAST_RUN.update({"kernel_counts": dev.kernel_counts(), "stats": stats})
+        if stats["p_unconverged"]:
+            import warnings
+            warnings.warn(f"{stats['p_unconverged']} pressure solve(s) stopped at maxiter above solver.pressure.tol "
+                          "(frozen operator: continued like the reference's cached-pyamg branch, solver.py:829-833)",
+                          RuntimeWarning, stacklevel=2)
     finally:
         dev.close()
     return fields, step, time

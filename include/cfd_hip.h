@@ -12,8 +12,9 @@
  *   - host arrays are the reference's numpy layout: C-order float64, shape
  *     (Ni+2, Nj+2) for ghosted cell fields [i][j] (j contiguous), (Ni+1, Nj) for
  *     i-face arrays, (Ni, Nj+1) for j-face arrays, (Ni, Nj) for interior arrays.
- *   - device layout: transposed planes [j][i], i contiguous, one ghost
- *     layer, row pitch padded to 256 B; j-slabs are contiguous row blocks.
+ *   - device layout: transposed planes [j][i], i contiguous, CFD_GHOST_ROWS
+ *     ghost rows below and above the interior (the innermost is the reference's ghost
+ *     layer), row pitch padded to 256 B; j-slabs are contiguous row blocks.
  *   - one context per GPU / per process; calls on one context must not overlap.
  */
 #ifndef CFD_HIP_H
@@ -84,6 +85,11 @@ typedef struct cfd_solve_stats {
     double mom_relres[2];    /* final |r|/|b| of u and v                            */
     double p_relres;         /* final |r|/|b| of the pressure correction            */
     double k_relres[2];
+    int32_t p_unconverged;   /* pressure solves since cfd_create that stopped at maxiter above the tolerance
+                              * (frozen operator: counted, the reference's cached-pyamg branch does not raise either,
+                              * solver.py:829-833; fresh operator: CFD_E_NOCONV like solver.py:842-844).  Transport
+                              * solves never end unconverged: CFD_E_NOCONV after a restart with four times maxiter */
+    int32_t reserved;
 } cfd_solve_stats;
 
 const char *cfd_last_error(void);
@@ -342,7 +348,23 @@ int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us);
  * 2 = momentum right-hand sides (+ continuity, + time-step minima), 8 / 9 = Chebyshev launches with two / one
  * right-hand sides.  cfd_probe_read returns how many launches were timed and their average duration.        */
 int cfd_probe(cfd_ctx *ctx, int kernel);
-int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us);
+/* avg_bytes_per_cell (may be NULL): mean ALGORITHMIC bytes per cell of the timed launches -- they differ from launch to
+ * launch for some kernels (the first two direction steps of a PCG solve skip the x / p_old planes: 40 / 56 / 64 B)  */
+int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us, double *avg_bytes_per_cell);
+/* Tuning / A-B switches of the kernel forms, for tests and measurements (results are the same bits either way unless
+ * noted; the library reads no environment variable): "cheb_stages" (1 / 2 / 4 Chebyshev iterations per launch),
+ * "cheb_prefetch" (1 / 2 rows of loads in flight per wave), "fuse_nut", "dt_lookahead", "fuse_resid" (0 / 1: the
+ * fusions of DESIGN.md section 3), "nt_stores" (-1 auto / 0 / 1: nontemporal stores of the streaming kernels),
+ * "march_ls" (rows per segment of the marching kernels, 0 = default), "mg_line" (-1 auto / 0 / 1: j-line smoother;
+ * changes the V-cycle, hence iteration counts, not the converged solution).  No counterpart in the reference.     */
+int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
+/* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels
+ * its run went through: [0] 4-iteration Chebyshev launches with two right-hand sides, [1] with one, [2] 2-iteration
+ * launches, [3] 1-iteration launches, [4] BiCGStab iterations, [5] marching flux launches, [6] of those with more
+ * than one column strip, [7] tile flux launches, [8] max number of fused multigrid levels in a V-cycle, [9] PCG
+ * iterations whose residual update ran inside the pre-smoother, [10] fused PCG direction steps, [11] V-cycles,
+ * [12] max number of levels smoothed by j-lines.  n <= 16 entries are written.  No counterpart in the reference.  */
+int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset);
 /* accumulated device time per phase since the last reset (HIP events), microseconds:
  * {bc, adv(rhs), mom, press, corr, cont, turb, dt}                                          */
 int cfd_phase_times(cfd_ctx *ctx, double out[8], int reset);

@@ -181,13 +181,15 @@ def ramp_initial_u(cfg, mesh):
     cfg["initial"]["u"] = cfg.pop("_u_ramp") * ramp
 
 
-def channel_forced(n=64, steps=3, turbulent=False, ratio_j=1.0, max_iter=2, seed=1234, tol=TIGHT, model="k_omega"):
+def channel_forced(n=64, steps=3, turbulent=False, ratio_j=1.0, max_iter=2, seed=1234, tol=TIGHT, model="k_omega",
+                   nj=None, name="channel_forced"):
     """Miniature of the 8192^2 benchmark workload: periodic-i channel,
-    walls, pressure-gradient forcing, perturbed parabolic initial u."""
-    mp = dict(length_i=1.0, length_j=1.0, count_i=n, count_j=n, ratio_i=1.0, ratio_j=ratio_j)
+    walls, pressure-gradient forcing, perturbed parabolic initial u (n x nj cells, square by default)."""
+    nj = n if nj is None else nj
+    mp = dict(length_i=1.0, length_j=1.0, count_i=n, count_j=nj, ratio_i=1.0, ratio_j=ratio_j)
     bc = {
-        "i_min": {"type": "periodic", "range": (0, n - 1)},
-        "i_max": {"type": "periodic", "range": (0, n - 1)},
+        "i_min": {"type": "periodic", "range": (0, nj - 1)},
+        "i_max": {"type": "periodic", "range": (0, nj - 1)},
         "j_min": {"type": "wall", "range": (0, n - 1)},
         "j_max": {"type": "wall", "range": (0, n - 1)},
         "pressure_reference": {"cell": (0, 0), "value": 0.0},
@@ -197,7 +199,7 @@ def channel_forced(n=64, steps=3, turbulent=False, ratio_j=1.0, max_iter=2, seed
     if turbulent:
         turb = {"enabled": True, "model": model, "update_interval": 1}
         init["scalars"] = {"k": 1.0e-4, "omega": 10.0}
-    cfg = _base("channel_forced", 1.0e-3,
+    cfg = _base(name, 1.0e-3,
                 {"cfl": 0.5, "cfl_diff": 0.5, "dt_max": 1.0e-3, "dt_min": 0.0, "max_steps": steps},
                 _solver("simple", max_iter, 0.0, tol=tol), bc, init, turbulence=turb,
                 forcing=(-0.1, 0.0))
@@ -231,4 +233,35 @@ SST_END_TO_END = {
     "half_cylinder_sst": (lambda: half_cylinder(turbulent=True, model="sst"), None),
     "channel_forced_sst_24": (lambda: channel_forced(n=24, steps=3, turbulent=True, ratio_j=1.04, model="sst"),
                               perturbed_parabola),
+}
+
+
+# Cases at sizes where the production kernels of the 8192^2 run are the ones that execute:
+# >= 3 column strips of the marching flux kernels (160 > 2 x 62), k_chebk<.,4> (both sides >= 64), three fused
+# multigrid levels (160x96 -> 80x48 -> 40x24 -> 20x12), PCG solves long enough for deferred residual updates.
+# channel_forced_64 / _komega_64 are the 64 x 64 miniatures SURVEY.md 8(c) lists.
+def _couette_large():
+    cfg, mp, kind = couette_piso(ni=160, nj=96, steps=3, dt=2.0e-3)
+    mp["ratio_j"] = 1.02
+    cfg["case_name"] = "couette_piso_160x96"
+    return cfg, mp, kind
+
+
+def _inout_large():
+    cfg, mp, kind = inlet_outlet_channel(ni=160, nj=96, steps=3)
+    mp["ratio_i"] = 1.005
+    mp["ratio_j"] = 1.02
+    cfg["case_name"] = "inlet_outlet_160x96"
+    return cfg, mp, kind
+
+
+LARGE_END_TO_END = {
+    "channel_forced_64": (lambda: channel_forced(n=64, steps=3), perturbed_parabola),
+    "channel_forced_komega_64": (lambda: channel_forced(n=64, steps=3, turbulent=True), perturbed_parabola),
+    "channel_forced_160x96": (lambda: channel_forced(n=160, nj=96, steps=3, ratio_j=1.02, name="channel_forced_160x96"),
+                              perturbed_parabola),
+    "channel_forced_komega_160x96": (lambda: channel_forced(n=160, nj=96, steps=3, ratio_j=1.02, turbulent=True,
+                                                            name="channel_forced_komega_160x96"), perturbed_parabola),
+    "inlet_outlet_160x96": (_inout_large, None),
+    "couette_piso_160x96": (_couette_large, perturbed_rest),
 }

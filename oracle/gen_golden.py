@@ -18,8 +18,9 @@ Three tiers, recorded in every file's `tier` entry:
      exact solve.  Tier C is cross-checked here against tier A (the committed logs of
      the real-pyamg run) before anything is written.
 
-Usage:  python oracle/gen_golden.py            (regenerates everything but the SST rows)
+Usage:  python oracle/gen_golden.py            (regenerates everything but the SST and the large rows)
         python oracle/gen_golden.py sst        (SST rows: ref_runs/sst_*, e2e_*sst*)
+        python oracle/gen_golden.py large      (func_rect_136x20, func_annulus_132x24, e2e_*_64_*, e2e_*_160x96_*)
 """
 from __future__ import annotations
 
@@ -135,7 +136,7 @@ def run_reference_case(ref_solver, ref_mesh, builder, fixup, tier):
 
 
 # ---------------------------------------------------------------- per-function vectors
-def function_vectors(ref_solver, ref_mesh, ref_bc, ref_turb, ref_post, kind, params, seed, bc_cfg, nu, tag):
+def function_vectors(ref_solver, ref_mesh, ref_bc, ref_turb, ref_post, kind, params, seed, bc_cfg, nu, tag, dense=True):
     mesh = ref_mesh_dict(ref_mesh, kind, params)
     ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
     rng = np.random.default_rng(seed)
@@ -183,14 +184,18 @@ def function_vectors(ref_solver, ref_mesh, ref_bc, ref_turb, ref_post, kind, par
     src = rng.standard_normal((ni, nj))
     out["in_source"] = src
     a_mat, b, ap2 = ref_solver._assemble_implicit_system(g["u"], mesh, nu_eff, dt, src, bc_cfg=bc_cfg)
-    out["sys_A"] = a_mat.toarray()
+    if dense:
+        out["sys_A"] = a_mat.toarray()
+    else:       # large meshes: CSR triplets instead of the dense matrix
+        csr = a_mat.tocsr()
+        out["sys_A_data"], out["sys_A_indices"], out["sys_A_indptr"] = csr.data, csr.indices, csr.indptr
     out["sys_b"], out["sys_ap"] = b, ap2
 
     cap = {}
     orig = ref_solver._solve_pressure_system
 
     def grab(a, bb, tol=1e-8, maxiter=200, amg_cache=None):
-        cap["A"], cap["b"] = a.toarray(), np.array(bb)
+        cap["A"], cap["b"] = (a.toarray() if dense else a.tocsr()), np.array(bb)
         return spla.spsolve(a.tocsc(), bb)
 
     ref_solver._solve_pressure_system = grab
@@ -199,7 +204,11 @@ def function_vectors(ref_solver, ref_mesh, ref_bc, ref_turb, ref_post, kind, par
         ref_solver.solve_pressure(h, mesh, dt, nu_eff, bc_cfg, a_p_override=ap, p_field=h["p"])
     finally:
         ref_solver._solve_pressure_system = orig
-    out["psys_A"], out["psys_b"] = cap["A"], cap["b"]
+    if dense:
+        out["psys_A"] = cap["A"]
+    else:
+        out["psys_A_data"], out["psys_A_indices"], out["psys_A_indptr"] = cap["A"].data, cap["A"].indices, cap["A"].indptr
+    out["psys_b"] = cap["b"]
     out["p_corr"] = h["p_corr"].copy()
 
     u0 = rng.standard_normal((ni, nj))
@@ -333,8 +342,44 @@ def main():
         remove_pyamg_standin()
 
 
+def main_large():
+    """python oracle/gen_golden.py large: per-function vectors on meshes wider than two column strips of the
+    marching kernels (>= 130 columns) and the end-to-end cases of cases.LARGE_END_TO_END (tier C: frozen
+    operator through the harness pyamg stand-in, CONFIG tolerances 1e-13)."""
+    OUT.mkdir(parents=True, exist_ok=True)
+    remove_pyamg_standin()
+    ref_solver, ref_mesh, ref_bc, ref_turb, ref_post = load_reference()
+    ni, nj = 136, 20
+    rect_bc = {
+        "i_min": {"type": "periodic", "range": (0, nj - 1)},
+        "i_max": {"type": "periodic", "range": (0, nj - 1)},
+        "j_min": {"type": "wall", "range": (0, ni - 1)},
+        "j_max": {"type": "symmetry", "range": (0, ni - 1)},
+        "pressure_reference": {"cell": (70, 3), "value": 0.25},
+    }
+    function_vectors(ref_solver, ref_mesh, ref_bc, ref_turb, ref_post, "rect",
+                     dict(length_i=3.0, length_j=0.5, count_i=ni, count_j=nj, ratio_i=1.01, ratio_j=1.1),
+                     21, rect_bc, 1.0e-3, "rect_136x20", dense=False)
+    nr, nt = 132, 24
+    function_vectors(ref_solver, ref_mesh, ref_bc, ref_turb, ref_post, "annulus",
+                     dict(radius_inner=0.5, radius_outer=6.0, count_r=nr, count_t=nt,
+                          theta_min=0.0, theta_max=float(np.pi), ratio_r=1.02, ratio_t=1.0),
+                     22, cases._half_cylinder_bc(nr, nt, True), 2.0e-2, "annulus_132x24", dense=False)
+    install_pyamg_standin()
+    try:
+        for name, (builder, fixup) in cases.LARGE_END_TO_END.items():
+            out = run_reference_case(ref_solver, ref_mesh, builder, fixup, "C")
+            out.pop("residual_log_text", None)
+            np.savez_compressed(OUT / f"e2e_{name}_frozen.npz", **out)
+            print(f"wrote e2e_{name}_frozen.npz  steps={int(out['step'])}", flush=True)
+    finally:
+        remove_pyamg_standin()
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sst":
         main_sst()
+    elif len(sys.argv) > 1 and sys.argv[1] == "large":
+        main_large()
     else:
         main()

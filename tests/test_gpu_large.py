@@ -1,0 +1,225 @@
+"""GPU parity at sizes where the production kernels of the 8192^2 run are the ones that execute (-m gpu).
+
+The small reference cases (<= 24 x 32 cells) run through the small-mesh forms of several kernels: the 4-iteration
+Chebyshev kernel needs both sides >= 64, the marching flux kernels have a strip seam only beyond 62 columns, a
+multigrid level is fused only from 16 x 16 cells up, and a PCG solve defers its residual update to the next
+pre-smoother only when it needs five or more iterations.  The cases here (oracle/cases.py LARGE_END_TO_END, golden
+vectors written by `python oracle/gen_golden.py large` from the reference itself) are 64 x 64 and 160 x 96 cells;
+each test asserts through cfd_kernel_counts WHICH kernel families its run went through.
+
+Tolerances as in test_gpu_parity.py: stencil kernels bit-exact against the reference's vectors, solved fields
+relative L2 <= 1e-10 (both sides solve to 1e-13), continuity history 2e-6 (7 printed digits).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_mesh, load_golden, mask_corners, rel_l2
+from oracle import cases
+from oracle import cfd_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL = 1.0e-10
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+
+
+def _run(name, tmp_path, tuning=None):
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    builder, fixup = cases.LARGE_END_TO_END[name]
+    cfg, mp, kind = builder()
+    cfg["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp, "path": tmp_path / "mesh" / "mesh.npz"}
+    cfg["paths"] = {"case_dir": tmp_path, "mesh_dir": tmp_path / "mesh", "states_dir": tmp_path / "states",
+                    "post_dir": tmp_path / "postproc"}
+    mesh = hip_mesh.make_mesh(cfg["mesh"])
+    if fixup is not None:
+        fixup(cfg, mesh)
+    cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+    if tuning:
+        cfg["solver"]["tuning"] = tuning
+    fields, step, time = hip_solver.run_case(cfg)
+    log = np.loadtxt(tmp_path / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+    return fields, step, time, log, dict(hip_solver.LAST_RUN), cfg, mesh
+
+
+def _compare(g, fields, step, time, log):
+    assert step == int(g["step"])
+    assert abs(time - float(g["time"])) <= 1e-11 * max(1.0, abs(float(g["time"])))
+    unorm = max(1.0, np.linalg.norm(g["field_u"].ravel()))
+    for key in [k for k in g if k.startswith("field_")]:
+        ref, mine = g[key], fields[key[6:]]
+        err = np.linalg.norm((mask_corners(mine) - mask_corners(ref)).ravel())
+        den = np.linalg.norm(mask_corners(ref).ravel())
+        assert err <= FIELD_TOL * den + 1e-12 * unorm, (key, err, den)
+    h = g["history"]
+    assert log.shape[0] == h.shape[0]
+    assert np.array_equal(log[:, 0], h[:, 0]) and np.array_equal(log[:, 2], h[:, 2])
+    assert np.all(np.abs(log[:, 3] - h[:, 3]) <= 2e-6 * h[:, 3] + 1e-12)
+    assert np.all(np.abs(log[:, 1] - h[:, 1]) <= 2e-6 * np.maximum(h[:, 1], 1e-30) + 1e-300)
+
+
+@pytest.mark.parametrize("name", list(cases.LARGE_END_TO_END))
+def test_production_kernels_against_reference(name, tmp_path):
+    """run_case on the GPU vs the reference (golden vectors) after 3 outer steps, and proof of the kernel path."""
+    g = load_golden(f"e2e_{name}_frozen.npz")
+    fields, step, time, log, last, cfg, mesh = _run(name, tmp_path)
+    _compare(g, fields, step, time, log)
+    kc = last["kernel_counts"]
+    big = "160x96" in name
+    # marching flux kernels; more than one 62-column strip on every mesh of this file
+    assert kc["flux_march"] > 0 and kc["flux_march_multistrip"] == kc["flux_march"] and kc["flux_tile"] == 0, kc
+    # fused V-cycle levels: 64x64 -> 32x32 -> 16x16 (-> 8x8 unfused): 3; 160x96 -> 80x48 -> 40x24 (-> 20x12): 3
+    assert kc["mg_fused_levels_max"] >= 3, kc
+    assert kc["cg_pq"] > 0 and kc["mg_deferred_resid"] > 0, kc       # PCG with residual updates inside the pre-smoother
+    if "couette" not in name:
+        # CFL-limited steps: the momentum (and k / omega) solves are 4-iteration Chebyshev launches, with both
+        # right-hand sides and, once one of them has converged, with one
+        assert kc["cheb4_2rhs"] > 0, kc
+        assert last["stats"]["mom_solver"] == "chebyshev", last["stats"]
+    if big and "couette" not in name and "inlet" not in name:
+        assert kc["cheb4_1rhs"] > 0, kc
+    assert last["stats"]["p_unconverged"] == 0
+
+
+@pytest.mark.parametrize("name", ["channel_forced_160x96", "channel_forced_komega_160x96"])
+def test_production_kernels_against_oracle(name, tmp_path):
+    """The same CONFIG through the pinned CPU oracle (direct solves, frozen pressure operator) and through the GPU:
+    five outer steps, i.e. beyond what the golden vectors hold."""
+    builder, fixup = cases.LARGE_END_TO_END[name]
+    cfg, mp, kind = builder()
+    cfg["time"]["max_steps"] = 5
+    mesh = orc.rect_mesh(**mp)
+    fixup(cfg, mesh)
+    ref, rstep, rtime, hist = orc.run_case(cfg, mesh, solver_mode="direct", freeze_pressure=True)
+
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    cfg2, mp2, _ = builder()
+    cfg2["time"]["max_steps"] = 5
+    cfg2["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp2, "path": tmp_path / "mesh" / "mesh.npz"}
+    cfg2["paths"] = {"case_dir": tmp_path, "mesh_dir": tmp_path / "mesh", "states_dir": tmp_path / "states",
+                     "post_dir": tmp_path / "postproc"}
+    mesh2 = hip_mesh.make_mesh(cfg2["mesh"])
+    fixup(cfg2, mesh2)
+    cfg2["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+    fields, step, time = hip_solver.run_case(cfg2)
+    assert step == rstep == 5 and abs(time - rtime) <= 1e-11 * rtime
+    unorm = np.linalg.norm(ref["u"].ravel())
+    for key in ("u", "v", "p", "k", "omega", "nu_t"):
+        if key not in ref:
+            continue
+        err = np.linalg.norm((mask_corners(fields[key]) - mask_corners(ref[key])).ravel())
+        den = np.linalg.norm(mask_corners(ref[key]).ravel())
+        assert err <= FIELD_TOL * den + 1e-12 * unorm, (key, err, den)
+    log = np.loadtxt(tmp_path / "postproc" / f"{cfg2['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+    conts = np.array([r["cont"] for r in hist])
+    assert np.all(np.abs(log[:, 3] - conts) <= 2e-6 * conts + 1e-12)
+    kc = hip_solver.LAST_RUN["kernel_counts"]
+    assert kc["cheb4_2rhs"] > 0 and kc["flux_march_multistrip"] > 0 and kc["mg_fused_levels_max"] >= 3 and kc["mg_deferred_resid"] > 0, kc
+
+
+@pytest.mark.parametrize("prefetch,nt", [(1, 0), (2, 0), (2, 1)])
+def test_chebyshev_kernel_forms_keep_the_bits(prefetch, nt, tmp_path):
+    """One or two rows of loads in flight per wave and nontemporal stores are scheduling / cache-policy choices:
+    the 160 x 96 k-omega run gives the same bits in every field."""
+    name = "channel_forced_komega_160x96"
+    base = _run(name, tmp_path / "base", tuning={"cheb_prefetch": 1, "nt_stores": 0})
+    other = _run(name, tmp_path / "other", tuning={"cheb_prefetch": prefetch, "nt_stores": nt})
+    for key in base[0]:
+        assert np.array_equal(base[0][key], other[0][key]), key
+    assert np.array_equal(base[3], other[3])
+    assert other[4]["kernel_counts"]["cheb4_2rhs"] > 0
+
+
+FUNC_LARGE = {
+    "annulus_132x24": cases._half_cylinder_bc(132, 24, True),
+    "rect_136x20": {
+        "i_min": {"type": "periodic", "range": (0, 19)},
+        "i_max": {"type": "periodic", "range": (0, 19)},
+        "j_min": {"type": "wall", "range": (0, 135)},
+        "j_max": {"type": "symmetry", "range": (0, 135)},
+        "pressure_reference": {"cell": (70, 3), "value": 0.25},
+    },
+}
+
+
+@pytest.mark.parametrize("tag", list(FUNC_LARGE))
+@pytest.mark.parametrize("marching", [True, False])
+def test_multistrip_kernels_against_reference_vectors(tag, marching):
+    """The reference's own functions (bc, eddy viscosity, conductances, Rhie-Chow flux, upwind advection, Green-Gauss
+    gradient, time step, pressure system, correction, continuity: solver.py:322-358, 455-513, 649-669, ...) on meshes
+    of 132 / 136 columns, i.e. three column strips of the marching kernels: bit-exact."""
+    from cfd_amd import _lib as L
+    from test_gpu_parity import _device_for
+    g = load_golden(f"func_{tag}.npz")
+    bc_cfg = FUNC_LARGE[tag]
+    mesh = golden_mesh(g)
+    ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
+    nu, dt = (float(x) for x in g["params"])
+    dev = _device_for(mesh, bc_cfg, nu)
+    dev.set_flux_kernels(marching, False)
+    dev.upload_fields({k: g[f"in_{k}"].copy() for k in ("u", "v", "p", "k", "omega", "nu_t")})
+    dev.apply_flow_bc()
+    for name in ("u", "v", "p", "k", "omega", "nu_t"):
+        assert np.array_equal(dev.download(L.FIELD_IDS[name]), g[f"bc_{name}"]), f"flow BC {name}"
+    dev.apply_turb_bc()
+    for name in ("k", "omega"):
+        assert np.array_equal(dev.download(L.FIELD_IDS[name]), g[f"tbc_{name}"]), f"turbulence BC {name}"
+    dev.eddy_viscosity()
+    assert np.array_equal(dev.download(L.F_NUT), g["nu_t"])
+    dev.momentum_diagonal(dt, 1.0)
+    assert np.array_equal(dev.download(L.F_AI, L.KIND_FACE_I), g["a_i"])
+    assert np.array_equal(dev.download(L.F_AJ, L.KIND_FACE_J), g["a_j"])
+    assert np.array_equal(dev.download(L.F_AP, L.KIND_CELL), g["a_p"])
+    fi, fj = dev.face_flux(rhie_chow=True)
+    assert np.array_equal(fi, g["flux_i"]) and np.array_equal(fj, g["flux_j"])
+    for name in ("u", "v", "k", "omega"):
+        assert np.array_equal(dev.advect(L.FIELD_IDS[name], g["flux_i"], g["flux_j"]), g[f"adv_{name}"]), name
+    for name in ("u", "v", "p", "k"):
+        assert np.array_equal(dev.grad(L.FIELD_IDS[name]), g[f"grad_{name}"]), name
+    d, da, dd = dev.compute_dt(0.5, 0.4, 0.0, 10.0)
+    assert d == float(g["dt"]) and (da, dd) == tuple(g["dt_limits"])
+
+    # momentum right-hand sides (marching kernel with three strips) vs the pinned oracle on the same state
+    state = {k: g[f"bc_{k}"].copy() for k in ("u", "v", "p")}
+    state["k"], state["omega"], state["nu_t"] = g["tbc_k"].copy(), g["tbc_omega"].copy(), g["nu_t"].copy()
+    nu_eff = nu + state["nu_t"][1:-1, 1:-1]
+    per_i, per_j = orc.periodic_axes(bc_cfg, ni, nj)
+    ap = orc.momentum_diag(mesh, nu_eff, dt)
+    ofi, ofj = orc.face_flux(state["u"], state["v"], state["p"], mesh, ap)
+    gp = orc.green_gauss(state["p"], mesh) + orc.green_gauss((2.0 / 3.0) * state["k"], mesh)
+    dev.momentum_rhs(dt)
+    for q, (name, fid) in enumerate((("u", L.F_BU), ("v", L.F_BV))):
+        src = orc.upwind_advection(state[name], mesh, ofi, ofj) - gp[..., q] + 0.0
+        _, b, _ = orc.transport_system(state[name], mesh, nu_eff, dt, src, per_i, per_j)
+        assert np.array_equal(dev.download(fid, L.KIND_CELL), b.reshape(ni, nj)), name
+
+    dev.pressure_solve()      # pressure right-hand side through the marching kernel, then MG-Krylov
+    pc = dev.download(L.F_PCORR)
+    assert rel_l2(pc[1:-1, 1:-1], g["p_corr"][1:-1, 1:-1]) < FIELD_TOL
+
+    dev.upload(L.F_PCORR, g["p_corr"])
+    snap = {k: np.zeros((ni + 2, nj + 2)) for k in ("u", "v", "p")}
+    for name, key in (("u", "in_u0"), ("v", "in_v0"), ("p", "in_p0")):
+        snap[name][1:-1, 1:-1] = g[key]
+    cur = {k: dev.download(L.FIELD_IDS[k]) for k in ("u", "v", "p")}
+    dev.upload_fields(snap)
+    dev.snapshot()
+    dev.upload_fields(cur)
+    dev.correct(0.7, 0.6, 0.3)
+    for name in ("u", "v", "p"):
+        assert np.array_equal(dev.download(L.FIELD_IDS[name])[1:-1, 1:-1], g[f"corr_{name}"][1:-1, 1:-1]), name
+    dev.upload_fields(state)
+    dev.momentum_diagonal(dt, 1.0)
+    cont = dev.continuity()
+    assert abs(cont - float(g["continuity"])) <= 1e-12 * float(g["continuity"])
+    kc = dev.kernel_counts()
+    if marching:
+        assert kc["flux_march_multistrip"] > 0 and kc["flux_tile"] == 0, kc
+    dev.close()

@@ -517,7 +517,7 @@ def test_marching_flux_kernels_match_tile_kernels(name, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["half_cylinder_komega", "channel_komega_5x20"])
-def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path, monkeypatch):
+def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path):
     """k-omega: nu_t evaluated inside the conductance pass (k_komega_coeffs: nu_t plane, a_i/a_j/a_P and the
     k / omega transport conductances in one launch) gives the bits of k_eddy_viscosity + 2 x k_diffusion_ap."""
     from cfd_amd import mesh as hip_mesh
@@ -526,7 +526,6 @@ def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path, monkeypat
         pytest.skip(f"no case {name}")
     out = {}
     for fuse in ("0", "1"):
-        monkeypatch.setenv("CFD_FUSE_NUT", fuse)
         d = tmp_path / f"fuse{fuse}"
         builder, fixup = cases.ALL_END_TO_END[name]
         cfg, mp, kind = builder()
@@ -536,6 +535,7 @@ def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path, monkeypat
         mesh = hip_mesh.make_mesh(cfg["mesh"])
         if fixup is not None:
             fixup(cfg, mesh)
+        cfg["solver"]["tuning"] = {"fuse_nut": int(fuse)}
         fields, step, time = hip_solver.run_case(cfg)
         out[fuse] = (fields, np.loadtxt(d / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2))
     assert out["0"][0]["nu_t"].any()
@@ -548,7 +548,7 @@ def test_fused_eddy_viscosity_matches_separate_kernels(name, tmp_path, monkeypat
                                            ("channel_forced_24", [(0.2, 0), (0.6, 3)]),
                                            # k-omega: only the advective minimum is taken ahead (nu_t changes in between)
                                            ("channel_forced_komega_24", None), ("half_cylinder_komega", None)])
-def test_time_step_minima_computed_ahead(name, schedule, tmp_path, monkeypatch):
+def test_time_step_minima_computed_ahead(name, schedule, tmp_path):
     """The pass that closes an inner iteration also evaluates the CFL / diffusive minima of the next outer step
     (same fields; in turbulent runs the advective one only).  Times, fields and logs keep the bits of the separate time-step kernel; with a CFL
     schedule the parameters differ from step to step and the values computed ahead must be discarded."""
@@ -556,7 +556,6 @@ def test_time_step_minima_computed_ahead(name, schedule, tmp_path, monkeypatch):
     from cfd_amd import solver as hip_solver
     out = {}
     for ahead in ("0", "1"):
-        monkeypatch.setenv("CFD_DT_LOOKAHEAD", ahead)
         d = tmp_path / f"ahead{ahead}"
         builder, fixup = cases.ALL_END_TO_END[name]
         cfg, mp, kind = builder()
@@ -569,6 +568,7 @@ def test_time_step_minima_computed_ahead(name, schedule, tmp_path, monkeypatch):
         mesh = hip_mesh.make_mesh(cfg["mesh"])
         if fixup is not None:
             fixup(cfg, mesh)
+        cfg["solver"]["tuning"] = {"dt_lookahead": int(ahead)}
         fields, step, time = hip_solver.run_case(cfg)
         out[ahead] = (fields, time, np.loadtxt(d / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2))
     assert out["0"][1] == out["1"][1] and out["0"][1] > 0.0
@@ -578,14 +578,13 @@ def test_time_step_minima_computed_ahead(name, schedule, tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["channel_forced_24", "half_cylinder_komega"])
-def test_residual_update_inside_the_presmoother(name, tmp_path, monkeypatch):
+def test_residual_update_inside_the_presmoother(name, tmp_path):
     """MG-PCG iterations whose |r| the host does not look at leave r = r - alpha q to the pre-smoother of the next
     V-cycle (k_mg_down_k<true, 3, true>): same bits as the separate k_cg_r pass, same iteration counts."""
     from cfd_amd import mesh as hip_mesh
     from cfd_amd import solver as hip_solver
     out = {}
     for fuse in ("0", "1"):
-        monkeypatch.setenv("CFD_FUSE_RESID", fuse)
         d = tmp_path / f"fuse{fuse}"
         builder, fixup = cases.ALL_END_TO_END[name]
         cfg, mp, kind = builder()
@@ -596,6 +595,7 @@ def test_residual_update_inside_the_presmoother(name, tmp_path, monkeypatch):
         mesh = hip_mesh.make_mesh(cfg["mesh"])
         if fixup is not None:
             fixup(cfg, mesh)
+        cfg["solver"]["tuning"] = {"fuse_resid": int(fuse)}
         fields, step, time = hip_solver.run_case(cfg)     # tight tolerances: 8+ PCG iterations per solve, several deferred
         out[fuse] = (fields, time, np.loadtxt(d / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2))
     assert out["0"][1] == out["1"][1]
@@ -605,7 +605,7 @@ def test_residual_update_inside_the_presmoother(name, tmp_path, monkeypatch):
 
 
 @pytest.mark.parametrize("turbulent", [False, True])
-def test_all_fusions_together_keep_the_bits_over_many_steps(turbulent, monkeypatch):
+def test_all_fusions_together_keep_the_bits_over_many_steps(turbulent):
     """The bench workload at 512^2 for 40 outer steps: eddy viscosity inside the conductance pass, time-step minima and
     momentum right-hand sides taken ahead, PCG residual update inside the pre-smoother -- all on vs all off gives the
     same u, v, p, k, omega, nu_t bit for bit and the same time."""
@@ -614,9 +614,9 @@ def test_all_fusions_together_keep_the_bits_over_many_steps(turbulent, monkeypat
     from cfd_amd.solver import advance_one_step
     out = {}
     for mode in ("0", "1"):
-        for var in ("CFD_FUSE_NUT", "CFD_DT_LOOKAHEAD", "CFD_FUSE_RESID", "CFD_RHS_LOOKAHEAD"):
-            monkeypatch.setenv(var, mode)
-        dev, ctl, cfg = bench.setup_device(512, turbulent, 2, 1e-8, 0)
+        tuning = {"fuse_nut": int(mode), "dt_lookahead": int(mode), "fuse_resid": int(mode), "cheb_prefetch": 1 + int(mode),
+                  "nt_stores": int(mode)}
+        dev, ctl, cfg = bench.setup_device(512, turbulent, 2, 1e-8, 0, tuning=tuning, lookahead=bool(int(mode)))
         t = 0.0
         for step in range(40):
             info = advance_one_step(dev, ctl, step)

@@ -21,7 +21,28 @@ FUNC_CASES = {
         "j_max": {"type": "symmetry", "range": (0, 7)},
         "pressure_reference": {"cell": (1, 2), "value": 0.25},
     }),
+    # wider than two column strips of the marching kernels (oracle/gen_golden.py large; matrices stored as CSR)
+    "annulus_132x24": ("annulus", cases._half_cylinder_bc(132, 24, True)),
+    "rect_136x20": ("rect", {
+        "i_min": {"type": "periodic", "range": (0, 19)},
+        "i_max": {"type": "periodic", "range": (0, 19)},
+        "j_min": {"type": "wall", "range": (0, 135)},
+        "j_max": {"type": "symmetry", "range": (0, 135)},
+        "pressure_reference": {"cell": (70, 3), "value": 0.25},
+    }),
 }
+NODE_ARGS = {"annulus_12x16": (0.5, 6.0, 12, 16, 0.0, float(np.pi), 1.15, 1.0), "rect_8x10": (1.0, 0.5, 8, 10, 1.1, 1.2),
+             "annulus_132x24": (0.5, 6.0, 132, 24, 0.0, float(np.pi), 1.02, 1.0), "rect_136x20": (3.0, 0.5, 136, 20, 1.01, 1.1)}
+
+
+def _same_matrix(a, g, key):
+    """The reference's matrix: dense for the small vector sets, CSR triplets for the large ones."""
+    if key in g:
+        return np.array_equal(a.toarray(), g[key])
+    import scipy.sparse as sp
+    ref = sp.csr_matrix((g[key + "_data"], g[key + "_indices"], g[key + "_indptr"]), shape=a.shape)
+    d = (a.tocsr() - ref).tocoo()
+    return d.nnz == 0 or not np.any(d.data != 0.0)
 
 
 def test_mesh_matches_committed_reference_mesh_bitwise():
@@ -41,10 +62,7 @@ def test_mesh_matches_reference_generators_bitwise(tag):
     mine = orc.metrics_from_nodes(node)
     for k in ref:
         assert np.array_equal(np.asarray(mine[k]), ref[k]), k
-    if tag.startswith("annulus"):
-        n2 = orc.annulus_nodes(0.5, 6.0, 12, 16, 0.0, float(np.pi), 1.15, 1.0)
-    else:
-        n2 = orc.rect_nodes(1.0, 0.5, 8, 10, 1.1, 1.2)
+    n2 = orc.annulus_nodes(*NODE_ARGS[tag]) if tag.startswith("annulus") else orc.rect_nodes(*NODE_ARGS[tag])
     assert np.array_equal(n2, node)
 
 
@@ -89,11 +107,11 @@ def test_per_function_vectors(tag):
 
     per_i, per_j = orc.periodic_axes(bc_cfg, ni, nj)
     a, b, ap2 = orc.transport_system(f["u"], mesh, nu_eff, dt, g["in_source"], per_i, per_j)
-    assert np.array_equal(a.toarray(), g["sys_A"])
+    assert _same_matrix(a, g, "sys_A")
     assert np.array_equal(b, g["sys_b"]) and np.array_equal(ap2, g["sys_ap"])
 
     a, b = orc.pressure_system(f["u"], f["v"], f["p"], mesh, ap, bc_cfg)
-    assert np.array_equal(a.toarray(), g["psys_A"])
+    assert _same_matrix(a, g, "psys_A")
     assert np.array_equal(b, g["psys_b"])
 
     h = {k: v.copy() for k, v in f.items()}
@@ -114,7 +132,7 @@ def test_per_function_vectors(tag):
 
 
 def _run_oracle(name, freeze):
-    builder, fixup = {**cases.ALL_END_TO_END, **cases.SST_END_TO_END}[name]
+    builder, fixup = {**cases.ALL_END_TO_END, **cases.SST_END_TO_END, **cases.LARGE_END_TO_END}[name]
     cfg, mp, kind = builder()
     mesh = orc.rect_mesh(**mp) if kind == "rect" else orc.annulus_mesh(**mp)
     if fixup is not None:
@@ -126,6 +144,8 @@ E2E = [(n, "fresh") for n in ("lam_channel", "inlet_outlet_channel", "couette_pi
                               "channel_forced_24")]
 E2E += [(n, "frozen") for n in cases.ALL_END_TO_END]
 E2E += [(n, "frozen") for n in cases.SST_END_TO_END]      # SST rows: fields include _S, _F1, _F2, _D_k, _D_omega, _d_wall
+# 64 x 64 and 160 x 96: the sizes at which the GPU run goes through its production kernels (tests/test_gpu_large.py)
+E2E += [(n, "frozen") for n in cases.LARGE_END_TO_END]
 
 
 @pytest.mark.parametrize("name,mode", E2E)
