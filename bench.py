@@ -9,22 +9,19 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
     torchrun ... bench.py --gpus N ...                        (one rank per GPU)
 
 The JSON line also carries
-  roofline     : the kernel with the largest share of device time, k_cg_pq (the MG-PCG direction step: p update,
-                 SpMV, (p,q) and the deferred x update in one marching pass; 15.3 % in profiles/r1p_*, just ahead of
-                 the momentum Chebyshev kernel k_chebk<2,4> with 14.8 %), timed live with HIP-event pairs around
-                 every launch inside the timed steps; achieved = 64 B/cell * Ni*Nj / avg duration (z, p_old, c_i,
-                 c_j, x read; p, q, x written; the diagonal is recomputed from the face planes).  --probe 8 / 9 / 7 /
-                 1 / 10 / 2 select the Chebyshev kernels (two / one right-hand side), the multigrid up / down / down
-                 with residual update kernels or the momentum RHS kernel; all of them are also reported once per run
-                 in roofline_other_kernels.
-                 traffic = HBM bytes per launch from the committed PMC passes of this command
-                 (profiles/r1p_pmc8192_bytes_per_cell.csv), quoted only for the single-GPU default size they
-                 were measured on.
-  strong_scaling_leg (N > 1): after the timed region the same --size x --size channel is split over the N GPUs and
-                 timed the same way; its value / the 1-GPU value is the strong-scaling speed-up.  The headline stays
-                 the weak-scaling figure (one --size x --size slab per GPU); --strong makes the split the headline.
-  cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum,
-                 factor-once LU pressure) timed on this host, bounded sample.
+  roofline     : the probed hot kernel with the largest share of device time (found live: one untimed step per
+                 candidate before the warm-up), timed with HIP-event pairs around EVERY launch inside the timed steps;
+                 achieved = sum of the algorithmic bytes of those launches / sum of their durations (the bytes differ
+                 per launch for some kernels: the first two PCG direction steps of a solve skip planes, the first
+                 Chebyshev launch has no x_{k-1}; the library reports them with the times), peak 8.0 TB/s.  --probe N
+                 forces a kernel.  All candidates are reported in roofline_other_kernels (one extra step each).
+                 traffic = HBM bytes per launch from the committed PMC passes of this command, quoted only for the
+                 single-GPU default size they were measured on.
+  N > 1        : the headline is BASELINE.json's configuration, the --size x --size channel split into N j-slabs
+                 ("scaling": "strong"); the weak-scaling variant (one --size x --size slab per GPU of a channel N
+                 times as high) is timed afterwards and reported as weak_scaling_leg (--weak makes it the headline).
+  cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum, factor-once LU pressure)
+                 timed on this host at 256^2, 512^2 and 1024^2 (--cpu-size), bounded by --cpu-budget seconds.
 """
 from __future__ import annotations
 
@@ -41,10 +38,30 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SMOOTHER_BYTES_PER_CELL = 42   # finest-level k_mg_up: x, e/4, b, c_i, c_j read (D recomputed from the faces) + x' written
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
 # 8192^2 (profiles/r1p_pmc8192_bytes_per_cell.csv; FETCH_SIZE calibrated x1.6 for 8-byte-per-lane loads)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {0: 55.59, 8: 108.32, 9: 70.53, 7: 41.65, 1: 33.87, 10: 49.93, 2: 126.08}
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {}       # filled from profiles/r2*_pmc8192_bytes_per_cell.csv when present
+PMC_KERNEL_OF_PROBE = {0: "k_cg_pq", 8: "k_chebk<2,4", 9: "k_chebk<1,4", 7: "k_mg_up_k<true", 1: "k_mg_down_k<true,3,false",
+                       10: "k_mg_down_k<true,3,true", 2: "k_flux_march<2"}
+
+
+def load_pmc_traffic():
+    """bytes per cell and launch of the probed kernels from the newest committed PMC summary (tools/pmc_summary.py)."""
+    files = sorted((REPO / "profiles").glob("r2*_pmc8192_bytes_per_cell.csv"))
+    if not files:
+        return None, {}
+    out = {}
+    for line in files[-1].read_text().splitlines():
+        if line.startswith("#") or not line.strip():
+            continue
+        cols = line.split(";")
+        for pid, key in PMC_KERNEL_OF_PROBE.items():
+            if cols[0].replace(" ", "").startswith(key.replace(" ", "")) and pid not in out:
+                try:
+                    out[pid] = float(cols[1])
+                except (IndexError, ValueError):
+                    pass
+    return files[-1].name, out
 
 
 def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, tuning=None, lookahead=True):
@@ -92,6 +109,25 @@ def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, t
     return dev, ctl, cfg
 
 
+def cpu_baselines(sizes, steps, max_iter, budget_s):
+    """cpu_baseline at several sizes (256^2, 512^2, 1024^2), stopping before a size whose estimated
+    cost (x8 per doubling of the side, measured 0.8 / 6.3 / 43 s per step) would exceed the time budget."""
+    out, spent, last = [], 0.0, None
+    for n_cpu, st in zip(sizes, steps):
+        if last is not None:
+            est = last[1] * (n_cpu / last[0]) ** 3 * (st + 1.5)
+            if spent + est > budget_s:
+                out.append({"size": n_cpu, "skipped": f"estimated {est:.0f} s would exceed --cpu-budget {budget_s:.0f} s"})
+                continue
+        t0 = time.perf_counter()
+        r = cpu_baseline(n_cpu, st, max_iter)
+        spent += time.perf_counter() - t0
+        last = (n_cpu, n_cpu * n_cpu / r["value"])
+        r["size"] = n_cpu
+        out.append(r)
+    return out
+
+
 def cpu_baseline(n_cpu, steps, max_iter):
     """Oracle with the reference's solver mix, on the host cores (1 effective thread)."""
     from cfd_amd.workloads import channel_forced_config
@@ -117,12 +153,25 @@ def cpu_baseline(n_cpu, steps, max_iter):
                       f"numpy/SuperLU single-threaded; total {time.perf_counter() - t0:.1f} s"}
 
 
-def strong_scaling_leg(args, n, world, local, barrier, torch, dist):
-    """N > 1, after the timed region: the same n x n channel split over the N GPUs, timed like the headline.  Any
-    (collective, hence symmetric) failure is reported in the JSON line instead of costing the headline."""
+KERNEL_NAMES = {
+    0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq2)",
+    1: "MG pre-smoother, finest level: 3 fused Jacobi sweeps + residual + restrict (k_mg_down_k<true,3>)",
+    2: "momentum RHS + continuity sum (+ next step's time-step minima in laminar runs, + grad(2/3 k) in k-omega runs), "
+       "marching Rhie-Chow flux kernel (k_flux_march<2>)",
+    8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>)",
+    9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
+    10: "MG pre-smoother with the PCG residual update folded in (k_mg_down_k<true,3,true>)",
+    7: "MG post-smoother, finest level: prolong + 3 fused Jacobi sweeps + (r,z) (k_mg_up_k<true,3>)"}
+CANDIDATES = (0, 8, 9, 7, 1, 10, 2)
+
+
+def second_leg(args, n, world, local, barrier, torch, dist, strong):
+    """N > 1, after the timed region: the other scaling mode, timed like the headline (barrier + synchronize on both
+    sides, max over ranks).  Any (collective, hence symmetric) failure is reported in the JSON line instead of costing
+    the headline."""
     from cfd_amd.solver import advance_one_step
     try:
-        sdev, sctl, _ = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1, args.transport)
+        sdev, sctl, _ = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if strong else world, args.transport)
         sstep = 0
         for _ in range(args.warmup):
             advance_one_step(sdev, sctl, sstep)
@@ -141,14 +190,17 @@ def strong_scaling_leg(args, n, world, local, barrier, torch, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         s_elapsed = float(t.item())
         sst = sdev.stats()
-        strong_leg = {"workload": f"the {n}x{n} channel as {world} j-slabs of {n}x{n // world} cells",
-                      "ms_per_step": 1e3 * s_elapsed / args.steps, "value": n * n / (s_elapsed / args.steps),
-                      "unit": "cell-updates/s", "steps": args.steps, "warmup": args.warmup,
-                      "pressure_iters_last_step": sst["p_iters"], "momentum_iters_last_step": sst["mom_iters"],
-                      "collectives_per_step": dict(zip(("halo_exchanges", "all_reduces", "all_gathers"),
-                                                       [(a - b) / args.steps for a, b in zip(sdev.comm_counts(), s0)]))}
+        cells = n * n if strong else n * n * world
+        leg = {"workload": (f"the {n}x{n} channel as {world} j-slabs of {n}x{n // world} cells" if strong else
+                            f"one {n}x{n} slab per GPU of a {n}x{n * world} channel of height {world}"),
+               "scaling": "strong" if strong else "weak",
+               "ms_per_step": 1e3 * s_elapsed / args.steps, "value": cells / (s_elapsed / args.steps),
+               "unit": "cell-updates/s", "steps": args.steps, "warmup": args.warmup,
+               "pressure_iters_last_step": sst["p_iters"], "momentum_iters_last_step": sst["mom_iters"],
+               "collectives_per_step": dict(zip(("halo_exchanges", "all_reduces", "all_gathers"),
+                                                [(a - b) / args.steps for a, b in zip(sdev.comm_counts(), s0)]))}
         sdev.close()
-        return strong_leg
+        return leg
     except Exception as exc:      # noqa: BLE001 - reported, not fatal
         return {"error": f"{type(exc).__name__}: {exc}"}
 
@@ -158,29 +210,32 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=8192, help="cells per side (per GPU)")
+    ap.add_argument("--size", type=int, default=8192, help="cells per side of the channel (strong scaling: of the whole "
+                    "channel, split over the GPUs; --weak: per GPU)")
     ap.add_argument("--turbulent", action="store_true", help="k-omega variant of the workload")
     ap.add_argument("--max-iter", type=int, default=2)
     ap.add_argument("--tol", type=float, default=1e-8)
-    ap.add_argument("--cpu-size", type=int, default=256)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-size", type=str, default="256,512,1024", help="sizes of the CPU baseline legs")
+    ap.add_argument("--cpu-steps", type=str, default="8,2,1", help="timed outer steps per CPU size (after one warm-up)")
+    ap.add_argument("--cpu-budget", type=float, default=170.0, help="seconds the CPU baseline may take in all; sizes "
+                    "whose estimated cost would exceed it are skipped and say so")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--probe", type=int, default=0, help="kernel id for the live roofline probe (8 = momentum Chebyshev, "
-                    "0 = PCG direction step, 7 / 1 / 10 = multigrid up / down / down with residual update, 2 = momentum RHS, "
-                    "9 = single-RHS Chebyshev)")
+    ap.add_argument("--probe", type=int, default=-1, help="kernel id of the live roofline probe (-1: the candidate with the "
+                    "largest share of device time; 0 = PCG direction step, 8 / 9 = momentum Chebyshev with two / one "
+                    "right-hand sides, 7 / 1 / 10 = multigrid up / down / down with residual update, 2 = momentum RHS)")
     ap.add_argument("--mg-sweeps", type=int, default=None, help="pre = post smoothing sweeps (2 or 3)")
     ap.add_argument("--mg-omegas", type=str, default=None, help="comma-separated damping factors, used cyclically")
-    ap.add_argument("--mg-omega", type=float, default=None, help="smoother damping of the even sweeps")
-    ap.add_argument("--mg-omega2", type=float, default=None, help="smoother damping of the odd sweeps")
+    ap.add_argument("--tuning", type=str, default=None, help="name=value,... passed to cfd_set_option (A/B measurements)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--transport", default=None, choices=("rccl", "torch"),
                     help="slab collectives: rccl = enqueued by the library itself (default under the nccl backend), "
                          "torch = torch.distributed callbacks (default under gloo, host-staged)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling: the --size x --size channel is split over the N GPUs (default: weak, one "
-                         "--size x --size slab per GPU)")
-    ap.add_argument("--no-strong-leg", action="store_true",
-                    help="N > 1: skip the strong-scaling leg that follows the (weak-scaling) timed region")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: headline = one --size x --size slab per GPU (weak scaling); default: BASELINE.json's "
+                         "configuration, the --size x --size channel split over the N GPUs (strong scaling)")
+    ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for older command lines)")
+    ap.add_argument("--no-second-leg", action="store_true",
+                    help="N > 1: skip the leg in the other scaling mode that follows the timed region")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use GPU 0 (with --backend gloo), numbers are not a measurement")
     args = ap.parse_args()
@@ -214,23 +269,47 @@ def main():
     from cfd_amd.solver import advance_one_step
 
     n = args.size
-    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if args.strong else world, args.transport)
-    cells_total = n * n if args.strong else world * n * n
+    strong = world > 1 and not args.weak
+    if strong and (n % world or (n // world) % 2 or n // world < 4):
+        raise SystemExit(f"--size {n} cannot be split into {world} even j-slabs")
+    tuning = None
+    if args.tuning:
+        tuning = {k: float(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))}
+    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if (strong or world == 1) else world,
+                                 args.transport, tuning=tuning)
+    cells_total = n * n if (strong or world == 1) else world * n * n
     cells_gpu = cells_total // world   # cells one launch on this GPU sweeps
     if args.mg_sweeps is not None or args.mg_omegas is not None:
         nu_s = args.mg_sweeps or 3
         dev.set_multigrid(nu_pre=nu_s, nu_post=nu_s,
                           omegas=[float(v) for v in args.mg_omegas.split(",")] if args.mg_omegas else None)
-    elif args.mg_omega is not None or args.mg_omega2 is not None:
-        dev.set_multigrid(nu_pre=2, nu_post=2, omega=args.mg_omega or 1.0,
-                          omega2=args.mg_omega2 if args.mg_omega2 is not None else 0.6)
     step = 0
     iters = []
+    # ---- which hot kernel has the largest share of device time?  One untimed step per candidate with the event-pair
+    # probe on it (these steps also serve as extra warm-up); the winner is probed inside the timed region.
+    shares = {}
+    probe_id = args.probe
+    if probe_id < 0:
+        advance_one_step(dev, ctl, step)      # first step: operators are built, nothing is representative yet
+        step += 1
+        for pid in CANDIDATES:
+            dev.probe(pid)
+            advance_one_step(dev, ctl, step)
+            step += 1
+            dev.synchronize()
+            cnt, us = dev.probe_read()
+            dev.probe(-1)
+            shares[pid] = cnt * us
+        probe_id = max(shares, key=shares.get)
+        if world > 1:      # every rank must probe the same kernel (it does not change the collectives, only the events)
+            t = torch.tensor([probe_id], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.int64)
+            dist.broadcast(t, 0)
+            probe_id = int(t.item())
     for _ in range(args.warmup):
         info = advance_one_step(dev, ctl, step)
         step += 1
     dev.synchronize()
-    dev.probe(args.probe)
+    dev.probe(probe_id)
     comm0 = dev.comm_counts()
     phase0 = dev.comm_counts_by_phase()
     barrier()
@@ -247,7 +326,7 @@ def main():
         t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_probe, probe_us = dev.probe_read()
+    n_probe, probe_us, probe_bpc = dev.probe_read(with_bytes=True)
     dev.probe(-1)
     comm1, phase1 = dev.comm_counts(), dev.comm_counts_by_phase()
     # ---- outside the timed region: per-phase device times of two more steps (event pairs with a host
@@ -262,27 +341,27 @@ def main():
         step += 1
     phases = dev.phase_times(reset=True)
     dev.enable_phase_timing(False)
-    # the other kernels BASELINE.json's target names (momentum RHS / Rhie-Chow, MG smoother, PCG step): one more
-    # step each with the event-pair probe on that kernel
+    # the other kernels BASELINE.json's target names (momentum RHS / Rhie-Chow, MG smoother, PCG step, Chebyshev): one
+    # more step each with the event-pair probe on that kernel
     others = {}
-    for pid in (2, 1, 10, 7, 0, 8):
-        if pid == args.probe:
+    for pid in CANDIDATES:
+        if pid == probe_id:
             continue
         dev.probe(pid)
         advance_one_step(dev, ctl, step)
         step += 1
         dev.synchronize()
-        others[pid] = dev.probe_read()
+        others[pid] = dev.probe_read(with_bytes=True)
         dev.probe(-1)
-    # ---- outside the timed region, N > 1 only: the SAME n x n channel split over the N GPUs (strong scaling, the
-    # figure BASELINE.json's target is worded in), timed like the headline: barrier + synchronize on both sides,
-    # max over ranks.  Reported beside the headline as "strong_scaling_leg"; value(N) / value(1 GPU) is its speed-up.
-    strong_leg = None
-    if world > 1 and not args.strong and not args.no_strong_leg and n % world == 0 and (n // world) % 2 == 0 and n // world >= 4:
-        strong_leg = strong_scaling_leg(args, n, world, local, barrier, torch, dist)
+    kcounts = dev.kernel_counts()
+    # ---- outside the timed region, N > 1 only: the other scaling mode
+    other_leg = None
+    if world > 1 and not args.no_second_leg:
+        if strong or (n % world == 0 and (n // world) % 2 == 0 and n // world >= 4):
+            other_leg = second_leg(args, n, world, local, barrier, torch, dist, strong=not strong)
     copy_gbs = None
     if rank == 0:
-        a = torch.empty(n * n, dtype=torch.float64, device="cuda")
+        a = torch.empty(cells_gpu, dtype=torch.float64, device="cuda")
         b = torch.empty_like(a)
         b.copy_(a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -291,48 +370,48 @@ def main():
             b.copy_(a)
         e1.record()
         torch.cuda.synchronize()
-        copy_gbs = 10 * 2 * 8.0 * n * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        copy_gbs = 10 * 2 * 8.0 * cells_gpu / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del a, b
     ms_per_step = 1000.0 * elapsed / args.steps
     value = cells_total / (elapsed / args.steps)
 
     out = None
     if rank == 0:
-        kernel_names = {0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq)",
-                        1: "MG pre-smoother, finest level: 3 fused Jacobi sweeps + residual + restrict (k_mg_down_k<true,3>)",
-                        2: "momentum RHS + continuity sum (+ next step's time-step minima in laminar runs, + grad(2/3 k) in k-omega runs), marching Rhie-Chow flux kernel (k_flux_march<2>)", 3: "batched momentum operator (k_bi_apply<2>)",
-                        8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>)",
-                        9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
-                        10: "MG pre-smoother with the PCG residual update folded in (k_mg_down_k<true,3,true>)",
-                        7: "MG post-smoother, finest level: prolong + 3 fused Jacobi sweeps + (r,z) (k_mg_up_k<true,3>)"}
-        bpc_table = {0: 64, 1: 34, 10: 50, 2: 128, 3: 72, 7: SMOOTHER_BYTES_PER_CELL, 8: 104, 9: 64}
-        bytes_per_cell = bpc_table[args.probe]
-        achieved = bytes_per_cell * cells_gpu / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
+        pmc_file, pmc = load_pmc_traffic()
+        achieved = probe_bpc * cells_gpu / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": (PMC_TRAFFIC_BYTES_PER_CELL_8192[args.probe] * cells_gpu
-                                if n == 8192 and world == 1 and not args.turbulent and args.probe in PMC_TRAFFIC_BYTES_PER_CELL_8192
-                                else None),
-                    "traffic_unit": "bytes per launch (PMC, committed profile)",
-                    "kernel": kernel_names.get(args.probe, str(args.probe)),
-                    "avg_us": probe_us, "launches_timed": n_probe, "bytes_per_cell": bytes_per_cell}
+                    "traffic": (pmc[probe_id] * cells_gpu
+                                if n == 8192 and world == 1 and not args.turbulent and probe_id in pmc else None),
+                    "traffic_unit": f"bytes per launch (PMC, profiles/{pmc_file})" if pmc_file else None,
+                    "kernel": KERNEL_NAMES.get(probe_id, str(probe_id)),
+                    "avg_us": probe_us, "launches_timed": n_probe,
+                    "bytes_per_cell": probe_bpc,
+                    "bytes_note": "mean ALGORITHMIC bytes per cell of the timed launches, reported by the library per launch "
+                                  "(PCG direction step: 40 / 56 / 64 B for the first / second / later steps of a solve)",
+                    "share_of_probed_device_time": (shares[probe_id] / sum(shares.values()) if shares else None)}
         it = np.array(iters)
+        if world == 1:
+            par = "1 GPU"
+        elif strong:
+            par = f"{world} j-slabs of {n}x{n // world} cells of the {n}x{n} channel (strong scaling)"
+        else:
+            par = f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel of height {world} (weak scaling)"
         out = {
             "metric": "cell-updates/s per outer step", "value": value, "unit": "cell-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.shared_gpu else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
-            "config": {"workload": f"synthetic {n}x{n} periodic channel with pressure-gradient forcing "
-                                   f"({'k-omega' if args.turbulent else 'laminar'}), SIMPLE max_iter={args.max_iter}, "
-                                   f"continuity_tol=0, cfl=cfl_diff=0.5, dt_max={cfg['time']['dt_max']:.3g}, rtol={args.tol:g}",
+            "config": {"workload": f"synthetic {n}x{n if (strong or world == 1) else n * world} periodic channel with "
+                                   f"pressure-gradient forcing ({'k-omega' if args.turbulent else 'laminar'}), SIMPLE "
+                                   f"max_iter={args.max_iter}, continuity_tol=0, cfl=cfl_diff=0.5, "
+                                   f"dt_max={cfg['time']['dt_max']:.3g}, rtol={args.tol:g}",
                        "cells_per_gpu": cells_gpu,
-                       "parallelism": "1 GPU" if world == 1 else
-                       (f"{world} j-slabs of {n}x{n // world} cells of the {n}x{n} channel (strong scaling)"
-                        if args.strong else
-                        f"{world} j-slabs of {n}x{n} cells of one {n}x{n * world} channel (height {world})")
-                       + ", halo rows + all-reduce + coarse-level all-gather "
-                       + ("enqueued by the library over RCCL" if dev.transport == "rccl" else
-                          f"through torch.distributed ({args.backend}) callbacks") + ", coarse multigrid levels replicated",
+                       "parallelism": par + ("" if world == 1 else
+                                             ", halo rows + all-reduce + coarse-level all-gather "
+                                             + ("enqueued by the library over RCCL" if dev.transport == "rccl" else
+                                                f"through torch.distributed ({args.backend}) callbacks")
+                                             + ", coarse multigrid levels replicated"),
                        "collectives_per_step": None if dev.comm is None else dict(zip(
                            ("halo_exchanges", "all_reduces", "all_gathers"),
                            [(a - b) / args.steps for a, b in zip(comm1, comm0)])),
@@ -341,13 +420,15 @@ def main():
                        "inner_iterations": args.max_iter,
                        "mean_momentum_iters": float(it[:, 0].mean()), "mean_pressure_iters": float(it[:, 1].mean()),
                        "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,
-                       "last_continuity_l2": info["cont"], "last_dt": info["dt"]},
+                       "last_continuity_l2": info["cont"], "last_dt": info["dt"],
+                       "kernel_launch_counts": kcounts},
             "roofline": roofline,
             "roofline_other_kernels": [
-                {"kernel": kernel_names[pid], "bytes_per_cell": bpc_table[pid], "avg_us": us, "launches_timed": cnt,
-                 "achieved": bpc_table[pid] * cells_gpu / (us * 1e-6) / 1e9 if cnt else None, "unit": "GB/s",
-                 "frac": bpc_table[pid] * cells_gpu / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if cnt else None}
-                for pid, (cnt, us) in others.items()],
+                {"kernel": KERNEL_NAMES[pid], "bytes_per_cell": bpc, "avg_us": us, "launches_timed": cnt,
+                 "achieved": bpc * cells_gpu / (us * 1e-6) / 1e9 if cnt else None, "unit": "GB/s",
+                 "frac": bpc * cells_gpu / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if cnt else None,
+                 "traffic": pmc[pid] * cells_gpu if (n == 8192 and world == 1 and not args.turbulent and pid in pmc) else None}
+                for pid, (cnt, us, bpc) in others.items()],
         }
         # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes of one
         # MG-PCG iteration over all levels: finest level 64 (k_cg_pq) + 24 (k_cg_r) + 34 (k_mg_down)
@@ -363,11 +444,19 @@ def main():
             "achieved_GBps": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 if press_s > 0 else None,
             "frac_of_hbm_peak": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
             "note": "includes the pressure right-hand side kernel and the host residual checks of the solve"}
-        out["strong_scaling_leg"] = strong_leg
+        out["weak_scaling_leg" if strong else "strong_scaling_leg"] = other_leg
         out["phase_ms_per_step"] = {k: 1e3 * v / extra_steps for k, v in phases.items()}
         out["device_copy_GBps"] = copy_gbs
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_steps, args.max_iter)
+            sizes = [int(v) for v in args.cpu_size.split(",") if v]
+            steps_l = [int(v) for v in args.cpu_steps.split(",") if v]
+            steps_l += [steps_l[-1]] * (len(sizes) - len(steps_l))
+            legs = cpu_baselines(sizes, steps_l, args.max_iter, args.cpu_budget)
+            done = [leg for leg in legs if "value" in leg]
+            head = dict(done[0]) if done else None      # the first size is the headline baseline, the others ride along
+            if head is not None:
+                head["other_sizes"] = legs[1:]
+            out["cpu_baseline"] = head
         else:
             out["cpu_baseline"] = None
     dev.close()

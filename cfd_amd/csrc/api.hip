@@ -200,7 +200,7 @@ int cfd_version(void) { return 100; }
 int cfd_ghost_rows(void) { return cfd::NG; }
 
 size_t cfd_workspace_bytes(int ni, int nj) {
-    if (ni < 1 || nj < 1) return 0;
+    if (ni < 1 || nj < 2) return 0;         // same bounds as cfd_create
     return workspace_bytes_impl(ni, nj, 1, 16, bc_bytes_for(ni, nj));
 }
 
@@ -215,8 +215,8 @@ int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_
 
 int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes, int rank,
                     int nranks, int min_slab_rows) {
-    if (!out || ni < 1 || nj < 1 || nranks < 1 || rank < 0 || rank >= nranks || min_slab_rows < 16) {
-        set_error("cfd_create: bad arguments");
+    if (!out || ni < 1 || nj < 2 || nranks < 1 || rank < 0 || rank >= nranks || min_slab_rows < 16) {
+        set_error("cfd_create: bad arguments (need ni >= 1, nj >= 2)");
         return CFD_E_ARG;
     }
     if (nranks > 1 && (nj % 2 || nj < 4)) {
@@ -228,26 +228,28 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     if (!h) { set_error("out of host memory"); return CFD_E_ARG; }
     Ctx *c = &h->c;
     c->device = device;
+    // every failure below leaves through cfd_destroy(h): stream, owned workspace, pinned buffer and events go with it
+    auto fail = [&](int rc) { cfd_destroy(h); return rc; };
     const size_t need = cfd_workspace_bytes_slab(ni, nj, nranks, min_slab_rows);
+    if (need == 0) { set_error("cfd_create: no workspace layout for %d x %d cells on %d ranks", ni, nj, nranks); return fail(CFD_E_ARG); }
     if (workspace) {
         if (workspace_bytes < need || ((uintptr_t)workspace & 255)) {
             set_error("workspace too small or not 256-byte aligned (need %zu bytes)", need);
-            delete h;
-            return CFD_E_ARG;
+            return fail(CFD_E_ARG);
         }
         c->ws = (char *)workspace;
         c->own_ws = false;
     } else {
         hipError_t e = hipMalloc((void **)&c->ws, need);
-        if (e != hipSuccess) { set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); delete h; return CFD_E_HIP; }
+        if (e != hipSuccess) { c->ws = nullptr; set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); return fail(CFD_E_HIP); }
         c->own_ws = true;
     }
     c->ws_bytes = need;
     hipError_t e = hipStreamCreate(&c->stream);
-    if (e != hipSuccess) { set_error("hipStreamCreate failed"); if (c->own_ws) hipFree(c->ws); delete h; return CFD_E_HIP; }
+    if (e != hipSuccess) { c->stream = nullptr; set_error("hipStreamCreate failed"); return fail(CFD_E_HIP); }
     c->own_stream = true;
     e = hipMemsetAsync(c->ws, 0, need, c->stream);
-    if (e != hipSuccess) { set_error("hipMemset failed"); return CFD_E_HIP; }
+    if (e != hipSuccess) { set_error("hipMemset failed"); return fail(CFD_E_HIP); }
 
     Geo gs{};
     const std::vector<Geo> lv = nranks > 1 ? level_geometry_slab(ni, nj, nranks, rank, min_slab_rows, c->l_agg, gs)
@@ -288,10 +290,10 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     c->partials = (double *)cv.take((size_t)8 * MAX_PARTIALS * sizeof(double));
     c->scal = (double *)cv.take(2048);
     c->bc_buf = (char *)cv.take(bc_bytes_for(ni, nj));
-    if (!c->bc_buf) { set_error("internal: workspace carve overflow"); return CFD_E_ARG; }
+    if (!c->bc_buf) { set_error("internal: workspace carve overflow"); return fail(CFD_E_ARG); }
     c->ws_used = cv.used;
     e = hipHostMalloc((void **)&c->h_scal, 256 * sizeof(double));
-    if (e != hipSuccess) { set_error("hipHostMalloc failed"); return CFD_E_HIP; }
+    if (e != hipSuccess) { c->h_scal = nullptr; set_error("hipHostMalloc failed"); return fail(CFD_E_HIP); }
     // carve the BC buffer
     {
         const size_t n = (size_t)(ni > nj ? ni : nj);
@@ -310,9 +312,9 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
         c->n_turb_vals = (int)(n * 16 * 4);
         c->turb_vals = (double *)bcv.take((size_t)c->n_turb_vals * 8);
     }
-    CFD_HIP(hipEventCreate(&c->ev0));
-    CFD_HIP(hipEventCreate(&c->ev1));
-    CFD_HIP(hipStreamSynchronize(c->stream));
+    if (hipEventCreate(&c->ev0) != hipSuccess) { c->ev0 = nullptr; set_error("hipEventCreate failed"); return fail(CFD_E_HIP); }
+    if (hipEventCreate(&c->ev1) != hipSuccess) { c->ev1 = nullptr; set_error("hipEventCreate failed"); return fail(CFD_E_HIP); }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { set_error("hipStreamSynchronize failed"); return fail(CFD_E_HIP); }
     *out = h;
     return CFD_OK;
 }

@@ -507,7 +507,7 @@ struct MomArgs {
 template <int MODE, bool KG, bool DT = false>
 __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, FluxMarch fm, MomArgs ma, double *bout,
                                                     double *partials) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     const int rc = MODE == 3 ? 0 : f.rc;

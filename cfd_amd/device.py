@@ -30,6 +30,11 @@ class Device:
     comm = None
     transport = None
 
+    @property
+    def pitch(self):
+        """Row pitch of the device planes in doubles (cell (i, j) sits at (j + GHOST_ROWS) * pitch + i + 2)."""
+        return int(self.lib.cfd_pitch(self._h))
+
     def comm_counts(self):
         """(halo exchanges, all-reduces, all-gathers) this context has issued so far (0, 0, 0 on one rank)."""
         cnt = (C.c_longlong * 3)()

@@ -8,7 +8,12 @@ vectors written by `python oracle/gen_golden.py large` from the reference itself
 each test asserts through cfd_kernel_counts WHICH kernel families its run went through.
 
 Tolerances as in test_gpu_parity.py: stencil kernels bit-exact against the reference's vectors, solved fields
-relative L2 <= 1e-10 (both sides solve to 1e-13), continuity history 2e-6 (7 printed digits).
+relative L2 <= 1e-10, continuity history 2e-6 (7 printed digits).  The golden runs solve momentum with ILU-BiCGStab
+to 1e-13 (the ILU factors make the last iteration overshoot: the pinned oracle with DIRECT solves reproduces them to
+2e-11 in p) and pressure with a sparse LU.  The pressure correction amplifies an error of the predictor by
+~1/dt x cond: with the Jacobi-type transport solvers of the GPU path stopped at 1e-13 p lands 7e-9 from the
+reference on the 160 x 96 k-omega case, with 1e-15 it lands 5e-11 -- so the GPU side of these comparisons runs its
+transport solves to 1e-15 ("both sides solve much tighter than the comparison tolerance").
 """
 import numpy as np
 import pytest
@@ -20,6 +25,7 @@ from oracle import cfd_oracle as orc
 pytestmark = pytest.mark.gpu
 
 FIELD_TOL = 1.0e-10
+TRANSPORT_TOL = 1.0e-15      # see the module docstring
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -40,7 +46,8 @@ def _run(name, tmp_path, tuning=None):
     mesh = hip_mesh.make_mesh(cfg["mesh"])
     if fixup is not None:
         fixup(cfg, mesh)
-    cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+    cfg["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
+    cfg["solver"]["momentum"]["tol"] = TRANSPORT_TOL
     if tuning:
         cfg["solver"]["tuning"] = tuning
     fields, step, time = hip_solver.run_case(cfg)
@@ -81,8 +88,9 @@ def test_production_kernels_against_reference(name, tmp_path):
         # CFL-limited steps: the momentum (and k / omega) solves are 4-iteration Chebyshev launches, with both
         # right-hand sides and, once one of them has converged, with one
         assert kc["cheb4_2rhs"] > 0, kc
-        assert last["stats"]["mom_solver"] == "chebyshev", last["stats"]
-    if big and "couette" not in name and "inlet" not in name:
+        if "komega" not in name:      # (the eddy viscosity of the k-omega run pushes the later steps to BiCGStab)
+            assert last["stats"]["mom_solver"] == "chebyshev", last["stats"]
+    if big and "couette" not in name and "komega" not in name:
         assert kc["cheb4_1rhs"] > 0, kc
     assert last["stats"]["p_unconverged"] == 0
 
@@ -107,7 +115,8 @@ def test_production_kernels_against_oracle(name, tmp_path):
                      "post_dir": tmp_path / "postproc"}
     mesh2 = hip_mesh.make_mesh(cfg2["mesh"])
     fixup(cfg2, mesh2)
-    cfg2["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
+    cfg2["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
+    cfg2["solver"]["momentum"]["tol"] = TRANSPORT_TOL
     fields, step, time = hip_solver.run_case(cfg2)
     assert step == rstep == 5 and abs(time - rtime) <= 1e-11 * rtime
     unorm = np.linalg.norm(ref["u"].ravel())
