@@ -92,6 +92,7 @@ SIGNATURES = {
     "cfd_turbulence_step": (C.c_int, [_vp, C.c_double]),
     "cfd_get_stats": (C.c_int, [_vp, C.POINTER(SolveStats)]),
     "cfd_bulk_velocity": (C.c_int, [_vp, C.c_int, _dp]),
+    "cfd_bulk_velocity_noalloc": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "cfd_eddy_viscosity": (C.c_int, [_vp]),
     "cfd_momentum_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),
     "cfd_face_flux": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),

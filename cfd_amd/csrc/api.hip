@@ -228,6 +228,7 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     if (!h) { set_error("out of host memory"); return CFD_E_ARG; }
     Ctx *c = &h->c;
     c->device = device;
+    (void)noalloc_prepare_device();      // set-up of cfd_bulk_velocity_noalloc on this GPU (it retries on its first call)
     // every failure below leaves through cfd_destroy(h): stream, owned workspace, pinned buffer and events go with it
     auto fail = [&](int rc) { cfd_destroy(h); return rc; };
     const size_t need = cfd_workspace_bytes_slab(ni, nj, nranks, min_slab_rows);

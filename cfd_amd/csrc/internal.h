@@ -376,6 +376,9 @@ int vcycle(Ctx *c, const double *r, double *z);
 int launch_spmv(Ctx *c, const OpDev &op, const double *x, double *y);
 int time_kernel(Ctx *c, int kernel, int reps, double *avg_us);
 
+// noalloc.hip: looks up this GPU's copy of the static scratch array (the current device's), once
+int noalloc_prepare_device();
+
 // api.hip
 int to_device(Ctx *c, const double *host, double *plane, int kind);
 int from_device(Ctx *c, const double *plane, double *host, int kind);

@@ -295,6 +295,20 @@ int cfd_get_stats(cfd_ctx *ctx, cfd_solve_stats *out);
 /* volume-weighted mean of u or v over the interior (post_processing.py:602-610)          */
 int cfd_bulk_velocity(cfd_ctx *ctx, int field_id, double *out);
 
+/* The same mean for callers that cannot allocate or synchronise: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its bulk velocity is one numpy line,
+ * post_processing.py:602-610).  Allocates nothing (no hipMalloc / hipFree, no allocating library routine), takes
+ * no context: field_dev and volume_dev are device planes in the library's layout -- cell (i, j) at
+ * (j + CFD_GHOST_ROWS) * pitch + i + 2, pitch >= ni + 4 doubles -- e.g. workspace + cfd_field_offset(ctx, id);
+ * out_dev receives three doubles ON THE DEVICE: {sum f V / sum V, sum f V, sum V}; both kernels are enqueued on
+ * hip_stream (NULL = the default stream) of the CURRENT device and the call returns without synchronising.  The
+ * partial sums live in a fixed 64 KiB device array of the library (one copy per GPU, held until the process ends):
+ * at most 32768 x 32768 cells, larger sizes are rejected (CFD_E_ARG); calls that overlap on one GPU race on that
+ * array, calls that follow each other (any sizes) do not.  Same kernels, tiles and summation order as
+ * cfd_bulk_velocity: the mean has the same bits.                                                              */
+int cfd_bulk_velocity_noalloc(const double *field_dev, const double *volume_dev, int ni, int nj, int pitch,
+                              void *hip_stream, double *out_dev);
+
 /* ---- fine-grained entry points (parity tests; README.md:196-205 function list) ------- */
 /* turbulence.eddy_viscosity, k-omega branch (turbulence.py:388-394): nu_t plane from k, omega */
 int cfd_eddy_viscosity(cfd_ctx *ctx);
