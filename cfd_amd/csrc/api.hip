@@ -334,6 +334,7 @@ int cfd_destroy(cfd_ctx *ctx) {
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->own_ws && c->ws) hipFree(c->ws);
     if (c->sst_mem) hipFree(c->sst_mem);
+    if (c->line_mem) hipFree(c->line_mem);
     if (c->wall_xy) hipFree(c->wall_xy);
     delete ctx;
     return CFD_OK;
@@ -375,6 +376,18 @@ int cfd_level_info(cfd_ctx *ctx, int *n_levels, int *first_replicated) {
     CTX(ctx);
     if (n_levels) *n_levels = (int)c->levels.size();
     if (first_replicated) *first_replicated = c->l_agg;
+    return CFD_OK;
+}
+
+int cfd_level_smoother(cfd_ctx *ctx, int level, int *ni, int *nj, double *aniso, int *line) {
+    CTX(ctx);
+    if (level < 0 || level >= (int)c->levels.size()) { set_error("cfd_level_smoother: no level %d", level); return CFD_E_ARG; }
+    if (!c->p_built) { set_error("pressure operator not built"); return CFD_E_STATE; }
+    const Level &L = c->levels[level];
+    if (ni) *ni = L.g.ni;
+    if (nj) *nj = L.g.nj;
+    if (aniso) *aniso = L.aniso;
+    if (line) *line = L.line ? 1 : 0;
     return CFD_OK;
 }
 
@@ -598,6 +611,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "nt_stores") c->nt_stores = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
     else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
+    else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }
+    else if (n == "mg_line_omega") { if (!(value > 0.0 && value <= 1.0)) { set_error("mg_line_omega: (0, 1]"); return CFD_E_ARG; } c->mg_line_omega = value; }
     else { set_error("cfd_set_option: unknown option '%s'", name); return CFD_E_ARG; }
     return CFD_OK;
 }

@@ -132,6 +132,11 @@ struct Level {
     Geo gs{};
     int joff = 0;
     double *s0 = nullptr, *s1 = nullptr, *s2 = nullptr;
+    // alternating line smoother (levels whose face couplings are strongly anisotropic): factors of the tridiagonal
+    // j-blocks (Thomas multipliers and inverse pivots), computed when the hierarchy is built
+    bool line = false;
+    double *lm = nullptr, *linv = nullptr;
+    double aniso = 1.0;           // max over the cells of strong / weak coupling (diagnostic, cfd_level_aniso)
 };
 
 // j-slab communication: callbacks supplied by the host (torch.distributed over RCCL in
@@ -264,6 +269,10 @@ struct Ctx {
     // (sst_mem, made by cfd_set_turbulence_model) so that k-omega and laminar runs do not pay for them
     int turb_model = 0;           // CFD_TURB_KOMEGA / CFD_TURB_SST
     char *sst_mem = nullptr;
+    char *line_mem = nullptr;      // Thomas factor planes of the line-smoothed multigrid levels (own allocation)
+    size_t line_mem_bytes = 0;
+    double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this
+    double mg_line_omega = 0.8;
     double *sst_S = nullptr, *sst_F1 = nullptr, *sst_F2 = nullptr, *sst_Dk = nullptr, *sst_Dw = nullptr, *sst_dw = nullptr;
     double *m_xc = nullptr, *m_yc = nullptr;     // cell centres
     double *wp = nullptr, *wi = nullptr, *wj = nullptr;   // omega transport operator (k keeps tp, ti, tj)

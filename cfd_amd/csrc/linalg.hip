@@ -1059,9 +1059,204 @@ __global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix 
     }
 }
 
+// ------------------------------------------------------------------ alternating line smoother
+// Point Jacobi smooths only along the strongly coupled direction of an anisotropic operator: on a wall-graded channel
+// (c_j / c_i up to (dx / dy_min)^2) or an annulus refined towards the cylinder (c_i >> c_j there) the V-cycle above
+// needs 50 .. 300 PCG iterations.  On levels whose strong / weak coupling ratio exceeds Ctx::mg_line_threshold the
+// smoother is block line Jacobi in BOTH directions plus one point sweep (pre: j-lines, i-lines, point; post: the
+// reverse, so the V-cycle stays symmetric):  x <- x + omega M^-1 (b - A x),  M = the diagonal plus the couplings
+// along the line direction inside a block.
+//   j-lines (k_line_j): lane = column, one wavefront marches down a segment of <= 32 rows = one block; Thomas
+//       elimination with factors precomputed per level (k_line_factor_j: multiplier m_j = c_s,j / p_{j-1}, inverse
+//       pivot 1 / p_j); the forward-eliminated right-hand sides wait in LDS for the backward pass.
+//   i-lines (k_line_i): lane = cell of the line, blocks of <= 62 cells between two halo lanes; parallel cyclic
+//       reduction over the 64 lanes (6 steps of wave shuffles), couplings across the block ends explicit.
+// Blocks are balanced (no short block at a wall, where the coupling is strongest).  CPU prototype and iteration
+// counts: tools/mg_proto_aniso.py.
+constexpr int LJ_MAX = 64;        // rows per j-block (LDS: 2 waves x 64 rows x 64 lanes x 8 B = 64 KiB per workgroup)
+constexpr int LJ_WAVES = 2;       // wavefronts per workgroup of k_line_j
+constexpr int LI_W = 62;          // cells per i-block
+
+struct LineGeo {
+    int nstrips, wstrip, nsegs, Ls;
+};
+static inline LineGeo line_geo(const Geo &g) {
+    LineGeo m;
+    m.nstrips = (g.ni + LI_W - 1) / LI_W;
+    m.wstrip = (g.ni + m.nstrips - 1) / m.nstrips;
+    m.nsegs = (g.nj + LJ_MAX - 1) / LJ_MAX;
+    m.Ls = (g.nj + m.nsegs - 1) / m.nsegs;
+    return m;
+}
+static inline int line_blocks(const LineGeo &m, int waves = 4) {
+    const long nb = ((long)m.nstrips * m.nsegs + waves - 1) / waves;
+    return (int)(nb < 2 * MAX_PARTIALS ? nb : 2 * MAX_PARTIALS);
+}
+
+// Thomas factors of the j-blocks: p_j0 = D_j0, p_j = D_j - c_s,j^2 / p_{j-1}; lm = c_s,j / p_{j-1} (0 on the first row
+// of a block), linv = 1 / p_j.  One thread per column and block.
+__global__ void k_line_factor_j(OpDev op, LineGeo lg, double *lm, double *linv) {
+    const Geo g = op.g;
+    const size_t P = g.pitch;
+    const long n = (long)g.ni * lg.nsegs;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(t % g.ni), seg = (int)(t / g.ni);
+        const int j0 = seg * lg.Ls, j1 = min(j0 + lg.Ls, g.nj);
+        double pprev = 1.0;
+        for (int j = j0; j < j1; ++j) {
+            const size_t c = g.cell(i, j);
+            const double cs = j > j0 ? op.cj[c] : 0.0;
+            const double m = j > j0 ? cs / pprev : 0.0;
+            const double pj = op.D[c] - m * cs;
+            lm[c] = m;
+            linv[c] = 1.0 / pj;
+            pprev = pj;
+        }
+        (void)P;
+    }
+}
+
+// max over the cells of (c_S + c_N) / (c_W + c_E) and of its inverse (cells without couplings in a direction skipped)
+__global__ void k_level_aniso(OpDev op, Tiling T, double *partials) {
+    const Geo g = op.g;
+    double mj = 0.0, mi = 0.0;
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+        const double a = op.ci[c] + op.ci[c + 1], b = op.cj[c] + op.cj[c + g.pitch];
+        if (a > 0.0 && b > 0.0) { mj = fmax(mj, b / a); mi = fmax(mi, a / b); }
+    }
+    __shared__ double sa[4], sb[4];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mj = fmax(mj, __shfl_down(mj, off, 64)); mi = fmax(mi, __shfl_down(mi, off, 64)); }
+    if ((tid & 63) == 0) { sa[tid >> 6] = mj; sb[tid >> 6] = mi; }
+    __syncthreads();
+    if (tid == 0) {      // negated: finished by a min (k_min_finish1) and a MIN all-reduce
+        partials[blockIdx.x] = -fmax(fmax(sa[0], sa[1]), fmax(sa[2], sa[3]));
+        partials[MAX_PARTIALS + blockIdx.x] = -fmax(fmax(sb[0], sb[1]), fmax(sb[2], sb[3]));
+    }
+}
+
+// One block j-line Jacobi sweep.  ZERO: the iterate is zero (first pre-smoothing sweep), xin is not read.
+template <bool ZERO>
+__global__ __launch_bounds__(64 * LJ_WAVES) void k_line_j(OpDev op, LineGeo lg, const double *lm, const double *linv, const double *b,
+                                                          const double *xin, double omega, double *xout) {
+    __shared__ double gl[LJ_WAVES][LJ_MAX][64];
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = gridDim.x * LJ_WAVES;
+    const size_t P = g.pitch;
+    for (int item = blockIdx.x * LJ_WAVES + wave; item < lg.nstrips * lg.nsegs; item += nw) {
+        const int strip = item % lg.nstrips, seg = item / lg.nstrips;
+        const int iraw = strip * lg.wstrip - 1 + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const bool out = lane >= 1 && lane <= lg.wstrip && iraw < g.ni;
+        const int j0 = seg * lg.Ls, j1 = min(j0 + lg.Ls, g.nj);
+        // old iterate on the rows just outside the block (explicit couplings); zero outside the domain
+        auto xrow = [&](int j) -> double {
+            if (ZERO) return 0.0;
+            const int mr = mem_row(j, g, op.per_j);
+            return (cvalid && mr >= 0) ? xin[(size_t)mr * P + colo] : 0.0;
+        };
+        const double xlo = xrow(j0 - 1), xhi = xrow(j1);
+        double gprev = 0.0;
+        for (int j = j0; j < j1; ++j) {
+            const size_t c = (size_t)(j + NG) * P + colo;
+            double rhs = b[c];
+            if (!ZERO) {
+                const double xc = cvalid ? xin[c] : 0.0;
+                const double xl = lane_left(xc), xr = lane_right(xc);
+                rhs += op.ci[c] * xl + op.ci[c + 1] * xr;
+            }
+            if (j == j0) rhs += op.cj[c] * xlo;
+            if (j == j1 - 1) rhs += op.cj[c + P] * xhi;
+            const double gj = rhs + lm[c] * gprev;
+            gl[wave][j - j0][lane] = gj;
+            gprev = gj;
+        }
+        double xnext = 0.0;
+        for (int j = j1 - 1; j >= j0; --j) {
+            const size_t c = (size_t)(j + NG) * P + colo;
+            const double cn = j < j1 - 1 ? op.cj[c + P] : 0.0;
+            const double xt = (gl[wave][j - j0][lane] + cn * xnext) * linv[c];
+            xnext = xt;
+            if (out) {
+                const double xo = ZERO ? 0.0 : xin[c];
+                xout[c] = xo + omega * (xt - xo);
+            }
+        }
+    }
+}
+
+// One block i-line Jacobi sweep: parallel cyclic reduction over the 64 lanes of a wavefront.
+__device__ __forceinline__ double shfl_from(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <bool ZERO>
+__global__ __launch_bounds__(256) void k_line_i(OpDev op, LineGeo lg, const double *b, const double *xin, double omega,
+                                                double *xout) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = gridDim.x * 4;
+    const size_t P = g.pitch;
+    for (int item = blockIdx.x * 4 + wave; item < lg.nstrips * lg.nsegs; item += nw) {
+        const int strip = item % lg.nstrips, seg = item / lg.nstrips;
+        const int iraw = strip * lg.wstrip - 1 + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const bool act = lane >= 1 && lane <= lg.wstrip && iraw < g.ni;      // unknowns of this block
+        const int j0 = seg * lg.Ls, j1 = min(j0 + lg.Ls, g.nj);
+        auto xrow = [&](int j) -> double {
+            if (ZERO) return 0.0;
+            const int mr = mem_row(j, g, op.per_j);
+            return (cvalid && mr >= 0) ? xin[(size_t)mr * P + colo] : 0.0;
+        };
+        double xs = xrow(j0 - 1), xc = xrow(j0);
+        for (int j = j0; j < j1; ++j) {
+            const size_t c = (size_t)(j + NG) * P + colo;
+            const double xn = xrow(j + 1);
+            // equation of the lane: a x_{l-1} + d x_l + cc x_{l+1} = r; halo / outside lanes hold their old value
+            double a = 0.0, cc = 0.0, d = 1.0, r = ZERO ? 0.0 : (cvalid ? xc : 0.0);
+            if (act) {
+                a = -op.ci[c]; cc = -op.ci[c + 1]; d = op.D[c];
+                r = b[c] + op.cj[c] * xs + op.cj[c + P] * xn;
+            }
+            double id = fast_rcp(d);
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1) {
+                const int lm_ = lane - s2, lp_ = lane + s2;
+                const bool hm = lm_ >= 0, hp = lp_ < 64;
+                const int sm_ = hm ? lm_ : lane, sp_ = hp ? lp_ : lane;
+                double am = shfl_from(a, sm_), cm = shfl_from(cc, sm_), rm = shfl_from(r, sm_), im = shfl_from(id, sm_);
+                double ap = shfl_from(a, sp_), cp = shfl_from(cc, sp_), rp = shfl_from(r, sp_), ip = shfl_from(id, sp_);
+                if (!hm) { am = 0.0; cm = 0.0; rm = 0.0; im = 1.0; }
+                if (!hp) { ap = 0.0; cp = 0.0; rp = 0.0; ip = 1.0; }
+                const double k1 = a * im, k2 = cc * ip;
+                d = d - cm * k1 - ap * k2;
+                r = r - rm * k1 - rp * k2;
+                a = -am * k1;
+                cc = -cp * k2;
+                id = fast_rcp(d);
+            }
+            const double xt = r * id;
+            if (act) {
+                const double xo = ZERO ? 0.0 : xc;
+                xout[c] = xo + omega * (xt - xo);
+            }
+            xs = xc; xc = xn;
+        }
+    }
+}
+
 // fused marching kernels: two or three sweeps per pass (a slab cut carries NG = 4 halo rows)
-static inline bool level_fusable(const Ctx *c, const Geo &F, const Geo &C) {
+static inline bool level_fusable(const Ctx *c, int lvl, const Geo &F, const Geo &C) {
     const bool k_ok = c->mg_pre == c->mg_post && (c->mg_pre == 2 || c->mg_pre == 3);
+    if (c->levels[lvl].line) return false;       // line-smoothed levels run their own kernels
     return c->mg_fused && k_ok && F.ni >= 16 && F.nj >= 16 && C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
 }
 static inline MarchGeo march_geo_k(const Geo &g, int K);
@@ -1879,7 +2074,87 @@ int build_pressure_hierarchy(Ctx *c) {
             CFD_TRY(halo_exchange(c, C.g, NG, C.ci, C.cj, C.D));
         }
     }
+    // ---- which levels get the alternating line smoother?  (strong / weak coupling ratio of the level's operator)
+    {
+        const int nl = (int)c->levels.size();
+        size_t need = 0;
+        for (int l = 0; l < nl; ++l) {
+            Level &L = c->levels[l];
+            L.line = false;
+            L.aniso = 1.0;
+            if (l == nl - 1 && nl > 1) continue;                 // the coarsest level is solved, not smoothed
+            const OpDev op = level_op(c, L);
+            const Tiling T = tiling(L.g);
+            hipLaunchKernelGGL(k_level_aniso, dim3(T.blocks), block2d(), 0, st, op, T, c->partials);
+            hipLaunchKernelGGL(k_min_finish1, dim3(1), dim3(256), 0, st, c->partials, T.blocks, c->scal + 72);
+            hipLaunchKernelGGL(k_min_finish1, dim3(1), dim3(256), 0, st, c->partials + MAX_PARTIALS, T.blocks, c->scal + 73);
+            CFD_HIP(hipGetLastError());
+            if (l < la) CFD_TRY(all_reduce(c, c->scal + 72, 2, 1));
+            double a[2];
+            CFD_TRY(read_scalars(c, 72, 2, a));
+            L.aniso = fmax(-a[0], -a[1]);
+            const bool big_enough = L.g.ni >= 4 && L.g.nj >= 4;
+            L.line = big_enough && (c->mg_line > 0 || (c->mg_line < 0 && L.aniso > c->mg_line_threshold));
+            if (L.line) need += 2 * L.g.plane_elems() * sizeof(double);
+        }
+        if (need > c->line_mem_bytes) {
+            if (c->line_mem) CFD_HIP(hipFree(c->line_mem));
+            c->line_mem = nullptr;
+            c->line_mem_bytes = 0;
+            CFD_HIP(hipMalloc((void **)&c->line_mem, need));
+            c->line_mem_bytes = need;
+        }
+        size_t off = 0;
+        int n_line = 0;
+        for (int l = 0; l < nl; ++l) {
+            Level &L = c->levels[l];
+            if (!L.line) continue;
+            ++n_line;
+            const size_t pb = L.g.plane_elems() * sizeof(double);
+            L.lm = (double *)(c->line_mem + off);
+            L.linv = (double *)(c->line_mem + off + pb);
+            off += 2 * pb;
+            const LineGeo lg = line_geo(L.g);
+            const long n = (long)L.g.ni * lg.nsegs;
+            const int nb = (int)std::min<long>((n + 255) / 256, 2048);
+            hipLaunchKernelGGL(k_line_factor_j, dim3(nb), dim3(256), 0, st, level_op(c, L), lg, L.lm, L.linv);
+            CFD_HIP(hipGetLastError());
+        }
+        if (n_line > c->kc[KC_MG_LINE_LEVELS_MAX]) c->kc[KC_MG_LINE_LEVELS_MAX] = n_line;
+    }
     c->p_built = true;
+    return CFD_OK;
+}
+
+// One pass of the alternating line smoother on level L: x_in (nullptr: zero) -> result; the planes ping-pong
+// between cur and oth, the result ends in *cur.  pre: j-lines, i-lines, point; post: point, i-lines, j-lines.
+static int line_smooth(Ctx *c, const Level &L, const OpDev &op, const double *rhs, double **cur, double **oth, bool post,
+                       bool zero_guess, bool distributed) {
+    hipStream_t st = c->stream;
+    const LineGeo lg = line_geo(L.g);
+    const dim3 grid(line_blocks(lg)), gridj(line_blocks(lg, LJ_WAVES));
+    const Tiling T = tiling(L.g);
+    const double om = c->mg_line_omega;
+    bool zero = zero_guess;
+    auto sweep = [&](int kind) -> int {         // 0: j-lines, 1: i-lines, 2: point
+        if (!zero && distributed) CFD_TRY(halo_exchange(c, L.g, 1, *cur));
+        if (kind == 0) {
+            if (zero) hipLaunchKernelGGL((k_line_j<true>), gridj, dim3(64 * LJ_WAVES), 0, st, op, lg, L.lm, L.linv, rhs, (const double *)nullptr, om, *oth);
+            else hipLaunchKernelGGL((k_line_j<false>), gridj, dim3(64 * LJ_WAVES), 0, st, op, lg, L.lm, L.linv, rhs, (const double *)*cur, om, *oth);
+        } else if (kind == 1) {
+            if (zero) hipLaunchKernelGGL((k_line_i<true>), grid, dim3(256), 0, st, op, lg, rhs, (const double *)nullptr, om, *oth);
+            else hipLaunchKernelGGL((k_line_i<false>), grid, dim3(256), 0, st, op, lg, rhs, (const double *)*cur, om, *oth);
+        } else {
+            if (zero) hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs, om, *oth);
+            else hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs, (const double *)*cur, om, *oth);
+        }
+        CFD_HIP(hipGetLastError());
+        std::swap(*cur, *oth);
+        zero = false;
+        return CFD_OK;
+    };
+    if (!post) { CFD_TRY(sweep(0)); CFD_TRY(sweep(1)); CFD_TRY(sweep(2)); }
+    else { CFD_TRY(sweep(2)); CFD_TRY(sweep(1)); CFD_TRY(sweep(0)); }
     return CFD_OK;
 }
 
@@ -1919,7 +2194,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         const bool to_agg = la > 0 && l + 1 == la;
         const Geo cg = coarse_view(c, l + 1);
         double *cb = to_agg ? C.s0 : C.b;
-        if (level_fusable(c, L.g, cg)) {
+        if (level_fusable(c, l, L.g, cg)) {
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
             if (++n_fused_levels > c->kc[KC_MG_FUSED_LEVELS_MAX]) c->kc[KC_MG_FUSED_LEVELS_MAX] = n_fused_levels;
@@ -1950,12 +2225,22 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 HaloSpec sp[2] = {{&L.g, KS, cur[l]}, {nullptr, 0, nullptr}};
                 int ns = 1;
                 x_sent[l] = 1;
-                if (l + 1 < la && l + 2 < nl && level_fusable(c, C.g, coarse_view(c, l + 2))) {
+                if (l + 1 < la && l + 2 < nl && level_fusable(c, l + 1, C.g, coarse_view(c, l + 2))) {
                     sp[ns++] = HaloSpec{&C.g, KS, cb};
                     rhs_sent[l + 1] = 1;
                 }
                 CFD_TRY(halo_exchange_multi(c, ns, sp));
             }
+        } else if (L.line) {
+            // alternating line smoother from a zero guess (its first sweep writes the other plane), then residual + restriction
+            std::swap(cur[l], oth[l]);
+            CFD_TRY(line_smooth(c, L, op, rhs[l], &cur[l], &oth[l], false, true, l < la));
+            CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
+            int fi, fj;
+            factors(L.g, cg, fi, fj);
+            const Tiling Tc = tiling(cg);
+            hipLaunchKernelGGL(k_mg_restrict, dim3(Tc.blocks), block2d(), 0, st, op, rhs[l], cur[l], cg, Tc, fi, fj, cb);
+            CFD_HIP(hipGetLastError());
         } else {
             const Tiling T = tiling(L.g);
             hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs[l], om, cur[l]);
@@ -2003,8 +2288,8 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         // (whose neighbouring rows are the halo), or the exchanged slab plane
         const double *e = cur[l + 1];
         if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
-        else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, level_fusable(c, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
-        if (level_fusable(c, L.g, cg)) {
+        else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, level_fusable(c, l, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
+        if (level_fusable(c, l, L.g, cg)) {
             const MarchGeo mgeo = march_geo_k(L.g, KS);
             const dim3 grid(march_blocks(mgeo));
             if (!x_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, cur[l]));
@@ -2033,6 +2318,11 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         int fi, fj;
         factors(L.g, cg, fi, fj);
         hipLaunchKernelGGL(k_mg_prolong, dim3(T.blocks), block2d(), 0, st, L.g, T, cg, fi, fj, e, c->mg_gamma, cur[l]);
+        if (L.line) {
+            CFD_HIP(hipGetLastError());
+            CFD_TRY(line_smooth(c, L, op, rhs[l], &cur[l], &oth[l], true, false, l < la));
+            continue;
+        }
         for (int s = 0; s < post; ++s) {
             CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
             hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs[l], cur[l], c->om_at(s), oth[l]);
@@ -2285,7 +2575,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     // (k_mg_down_k<true, 3, true>): r ping-pongs between the right-hand side plane and kry[1].  Needs the three-sweep
     // marching kernels on the finest level; on j-slabs q crosses the cuts in place of r.
     const bool can_defer = c->fuse_resid && fused && c->levels.size() > 1 && c->mg_pre == 3 && c->mg_post == 3 &&
-                           level_fusable(c, L0.g, coarse_view(c, 1));
+                           level_fusable(c, 0, L0.g, coarse_view(c, 1));
     double *r_other = c->kry[1];
     bool deferred = false;
     int deferred_gen = 0;
@@ -2476,7 +2766,7 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us) {
                 case 1: {
                     if (!c->p_built) { set_error("pressure operator not built"); return CFD_E_STATE; }
                     const OpDev op = level_op(c, c->levels[0]);
-                    if (c->levels.size() > 1 && level_fusable(c, c->levels[0].g, coarse_view(c, 1))) {
+                    if (c->levels.size() > 1 && level_fusable(c, 0, c->levels[0].g, coarse_view(c, 1))) {
                         const MarchGeo mgeo = march_geo(g);
                         hipLaunchKernelGGL((k_mg_up<true>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, c->p_diag, c->kry[1],
                                            c->kry[4], c->levels[1].g, c->levels[1].x, c->mg_gamma, c->om_at(0), c->om_at(1), c->kry[5], c->partials);

@@ -388,6 +388,17 @@ class Device:
         check(self.lib.cfd_probe_read(self._h, C.byref(n), C.byref(us), C.byref(bpc)))
         return (n.value, us.value, bpc.value) if with_bytes else (n.value, us.value)
 
+    def level_smoothers(self):
+        """[(ni, nj, strong / weak coupling ratio, line-smoothed?)] per multigrid level of the built pressure hierarchy."""
+        n, first = C.c_int(), C.c_int()
+        check(self.lib.cfd_level_info(self._h, C.byref(n), C.byref(first)))
+        out = []
+        for lvl in range(n.value):
+            ni, nj, an, ln = C.c_int(), C.c_int(), C.c_double(), C.c_int()
+            check(self.lib.cfd_level_smoother(self._h, lvl, C.byref(ni), C.byref(nj), C.byref(an), C.byref(ln)))
+            out.append((ni.value, nj.value, an.value, bool(ln.value)))
+        return out
+
     def set_option(self, name, value):
         """Tuning / A-B switch of a kernel form (include/cfd_hip.h: cfd_set_option)."""
         check(self.lib.cfd_set_option(self._h, str(name).encode(), float(value)))

@@ -148,6 +148,11 @@ int cfd_comm_counts_by_phase(cfd_ctx *ctx, long long counts[27]);
 int cfd_exchange_field(cfd_ctx *ctx, int field_id);
 /* number of multigrid levels and index of the first replicated one (0 on a single rank)         */
 int cfd_level_info(cfd_ctx *ctx, int *n_levels, int *first_replicated);
+/* multigrid level `level` of the built pressure hierarchy: its size, the largest strong / weak coupling ratio of
+ * its operator (max over the cells of (c_S + c_N) / (c_W + c_E) and of the inverse) and whether it is smoothed by
+ * alternating block lines (ratio above "mg_line_threshold", default 10) instead of point Jacobi.  The line smoother
+ * replaces pyamg's strength-of-connection coarsening (solver.py:821-833) as the answer to stretched meshes.   */
+int cfd_level_smoother(cfd_ctx *ctx, int level, int *ni, int *nj, double *aniso, int *line);
 
 int cfd_set_stream(cfd_ctx *ctx, void *hip_stream);
 int cfd_synchronize(cfd_ctx *ctx);
@@ -369,8 +374,9 @@ int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us, double *avg_bytes_p
  * noted; the library reads no environment variable): "cheb_stages" (1 / 2 / 4 Chebyshev iterations per launch),
  * "cheb_prefetch" (1 / 2 rows of loads in flight per wave), "fuse_nut", "dt_lookahead", "fuse_resid" (0 / 1: the
  * fusions of DESIGN.md section 3), "nt_stores" (-1 auto / 0 / 1: nontemporal stores of the streaming kernels),
- * "march_ls" (rows per segment of the marching kernels, 0 = default), "mg_line" (-1 auto / 0 / 1: j-line smoother;
- * changes the V-cycle, hence iteration counts, not the converged solution).  No counterpart in the reference.     */
+ * "march_ls" (rows per segment of the marching kernels, 0 = default), "mg_line" (-1 auto / 0 / 1: alternating line smoother
+ * on the anisotropic / no / all levels; with "mg_line_threshold" and "mg_line_omega" it changes the V-cycle, hence
+ * iteration counts, not the converged solution).  No counterpart in the reference.     */
 int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
 /* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels
  * its run went through: [0] 4-iteration Chebyshev launches with two right-hand sides, [1] with one, [2] 2-iteration

@@ -48,8 +48,10 @@ def _run(name, tmp_path, tuning=None):
         fixup(cfg, mesh)
     cfg["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
     cfg["solver"]["momentum"]["tol"] = TRANSPORT_TOL
-    if tuning:
-        cfg["solver"]["tuning"] = tuning
+    # the 160 x 96 meshes are graded (max / min dy = 6.6, coupling ratio up to 18): left alone, their multigrid levels
+    # would be line-smoothed; these tests are about the kernels of the uniform 8192^2 run, so point smoothing is forced
+    # (the line-smoothed path has its own tests below)
+    cfg["solver"]["tuning"] = dict({"mg_line": 0}, **(tuning or {}))
     fields, step, time = hip_solver.run_case(cfg)
     log = np.loadtxt(tmp_path / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
     return fields, step, time, log, dict(hip_solver.LAST_RUN), cfg, mesh
@@ -117,6 +119,7 @@ def test_production_kernels_against_oracle(name, tmp_path):
     fixup(cfg2, mesh2)
     cfg2["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
     cfg2["solver"]["momentum"]["tol"] = TRANSPORT_TOL
+    cfg2["solver"]["tuning"] = {"mg_line": 0}
     fields, step, time = hip_solver.run_case(cfg2)
     assert step == rstep == 5 and abs(time - rtime) <= 1e-11 * rtime
     unorm = np.linalg.norm(ref["u"].ravel())
@@ -232,3 +235,97 @@ def test_multistrip_kernels_against_reference_vectors(tag, marching):
     if marching:
         assert kc["flux_march_multistrip"] > 0 and kc["flux_tile"] == 0, kc
     dev.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# stretched meshes: alternating line smoother (the reference's real cases are wall-graded, Runs/*/config.py ratio_j 1.03)
+# ---------------------------------------------------------------------------------------------------------------------
+def _krylov_case(mesh, bc, per_i, per_j, mode, tol=1e-8):
+    from test_gpu_parity import _device_for
+    ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
+    dev = _device_for(mesh, bc, 1e-3, turbulent=False)
+    dev.set_option("mg_line", mode)
+    dev.upload_fields({k: np.zeros((ni + 2, nj + 2)) for k in ("u", "v", "p", "nu_t")})
+    dev.momentum_diagonal(3e-3, 1.0)
+    ci, cj, diag, _ = dev.pressure_system()
+    a = orc.five_point_matrix(diag, ci[:-1], ci[1:], cj[:, :-1], cj[:, 1:], per_i, per_j)
+    x_true = np.random.default_rng(1).standard_normal((ni, nj))
+    b = a.dot(x_true.ravel()).reshape(ni, nj)
+    sol, iters, relres = dev.pressure_krylov(b, tol=tol, maxiter=400)
+    true_res = np.linalg.norm(a.dot(sol.ravel()) - b.ravel()) / np.linalg.norm(b.ravel())
+    levels = dev.level_smoothers()
+    solver = dev.stats()["p_solver"]
+    dev.close()
+    return iters, relres, true_res, levels, solver
+
+
+@pytest.mark.parametrize("tag", ["channel_128_r1.04", "channel_256_Lx4", "annulus_132x24", "annulus_512x256", "inout_257x129"])
+def test_line_smoother_on_stretched_meshes(tag):
+    """MG-Krylov iterations at rtol 1e-8 with point Jacobi and with the alternating line smoother (chosen by itself from
+    the level's coupling ratio): the same solution (true residual from the scipy matrix), 3-5 x fewer iterations, at most
+    15 on the wall-graded 128 x 128 channel with growth ratio 1.04 (max / min dy = 146) that needed ~75."""
+    from test_gpu_parity import _bc_variant
+    if tag == "channel_128_r1.04":
+        mesh, bc, per, bound = orc.rect_mesh(1.0, 1.0, 128, 128, 1.0, 1.04), _bc_variant("per_i", 128, 128), (True, False), 15
+    elif tag == "channel_256_Lx4":
+        mesh, bc, per, bound = orc.rect_mesh(4.0, 1.0, 256, 256, 1.0, 1.0118), _bc_variant("per_i", 256, 256), (True, False), 24
+    elif tag == "annulus_132x24":
+        mesh, bc, per, bound = (orc.annulus_mesh(0.5, 6.0, 132, 24, 0.0, float(np.pi), 1.02, 1.0),
+                                cases._half_cylinder_bc(132, 24, False), (False, False), 16)
+    elif tag == "annulus_512x256":
+        mesh, bc, per, bound = (orc.annulus_mesh(0.5, 20.0, 512, 256, 0.0, float(np.pi), 1.012, 1.0),
+                                cases._half_cylinder_bc(512, 256, False), (False, False), 15)
+    else:
+        mesh, bc, per, bound = orc.rect_mesh(2.0, 1.0, 257, 129, 1.0, 1.02), _bc_variant("inout", 257, 129), (False, False), 15
+    it_point, rr_point, res_point, lv_point, _ = _krylov_case(mesh, bc, per[0], per[1], 0)
+    it_line, rr_line, res_line, lv_line, solver = _krylov_case(mesh, bc, per[0], per[1], -1)
+    assert lv_line[0][2] > 10.0 and lv_line[0][3] and not any(l[3] for l in lv_point), (lv_line, lv_point)
+    assert res_point <= 2e-8 and res_line <= 2e-8 and rr_line <= 1e-8
+    assert solver == "mg-pcg"                                  # the line-smoothed V-cycle is a symmetric preconditioner
+    assert it_line <= bound and 2 * it_line <= it_point, (it_line, it_point)
+
+
+def test_line_smoother_leaves_uniform_meshes_alone():
+    from test_gpu_parity import _bc_variant
+    mesh = orc.rect_mesh(1.0, 1.0, 256, 256, 1.0, 1.0)
+    it, rr, res, levels, _ = _krylov_case(mesh, _bc_variant("per_i", 256, 256), True, False, -1)
+    # (ratio 2 = the wall rows, which have one j-face only)
+    assert not any(l[3] for l in levels) and max(l[2] for l in levels) < 2.5 and it <= 7
+
+
+def test_graded_komega_channel_against_oracle(tmp_path):
+    """128 x 128 k-omega channel, wall-graded with growth ratio 1.04 (the stretching of the reference's own runs, at a
+    size where the line-smoothed multigrid levels, the multi-strip flux kernels and BiCGStab / Chebyshev all run):
+    three outer steps against the pinned CPU oracle with direct solves."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+
+    def build():
+        return cases.channel_forced(n=128, steps=3, turbulent=True, ratio_j=1.04, name="channel_graded_komega_128")
+
+    cfg, mp, kind = build()
+    mesh = orc.rect_mesh(**mp)
+    cases.perturbed_parabola(cfg, mesh)
+    ref, rstep, rtime, hist = orc.run_case(cfg, mesh, solver_mode="direct", freeze_pressure=True)
+    cfg2, mp2, _ = build()
+    cfg2["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp2, "path": tmp_path / "mesh" / "mesh.npz"}
+    cfg2["paths"] = {"case_dir": tmp_path, "mesh_dir": tmp_path / "mesh", "states_dir": tmp_path / "states",
+                     "post_dir": tmp_path / "postproc"}
+    mesh2 = hip_mesh.make_mesh(cfg2["mesh"])
+    cases.perturbed_parabola(cfg2, mesh2)
+    cfg2["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 4000}
+    cfg2["solver"]["momentum"]["tol"] = TRANSPORT_TOL
+    cfg2["solver"]["momentum"]["maxiter"] = 4000
+    fields, step, time = hip_solver.run_case(cfg2)
+    assert step == rstep == 3 and abs(time - rtime) <= 1e-11 * rtime
+    unorm = np.linalg.norm(ref["u"].ravel())
+    for key in ("u", "v", "p", "k", "omega", "nu_t"):
+        err = np.linalg.norm((mask_corners(fields[key]) - mask_corners(ref[key])).ravel())
+        den = np.linalg.norm(mask_corners(ref[key]).ravel())
+        assert err <= FIELD_TOL * den + 1e-12 * unorm, (key, err, den)
+    log = np.loadtxt(tmp_path / "postproc" / f"{cfg2['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+    conts = np.array([r["cont"] for r in hist])
+    assert np.all(np.abs(log[:, 3] - conts) <= 2e-6 * conts + 1e-12)
+    last = hip_solver.LAST_RUN
+    assert last["kernel_counts"]["mg_line_levels_max"] >= 3 and last["stats"]["p_unconverged"] == 0, last
+    assert last["stats"]["p_iters"] <= 40, last["stats"]           # rtol 1e-13; point Jacobi needs > 150 here
