@@ -64,7 +64,35 @@ def load_pmc_traffic():
     return files[-1].name, out
 
 
-def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, tuning=None, lookahead=True):
+def setup_annulus(nr, nt, max_iter, tol, device, tuning=None):
+    """Curvilinear variant (--mesh annulus): nr x nt half annulus around a cylinder, metrics computed on the device
+    from the node grid (cfd_mesh_from_nodes), single GPU."""
+    from cfd_amd import _lib as L
+    from cfd_amd.bc import BoundaryGeometry
+    from cfd_amd.device import Device
+    from cfd_amd.mesh import generate_annulus_nodes
+    from cfd_amd.solver import StepControl, configure_device
+    from cfd_amd.workloads import half_annulus_config
+
+    cfg, mp = half_annulus_config(nr, nt, max_iter, tol)
+    if tuning:
+        cfg["solver"]["tuning"] = dict(tuning)
+    node = generate_annulus_nodes(**mp)
+    dev = Device(nr, nt, device)
+    dev.mesh_from_nodes(node)
+    ctl = StepControl(cfg)
+    configure_device(dev, cfg, BoundaryGeometry.from_nodes(node), cfg["physics"]["nu"], ctl.turb_on)
+    del node
+    f = np.zeros((nr + 2, nt + 2))
+    f[1:-1, 1:-1] = 1.0
+    dev.upload(L.F_U, f)
+    f[:] = 0.0
+    for fid in (L.F_V, L.F_P, L.F_NUT):
+        dev.upload(fid, f)
+    return dev, ctl, cfg
+
+
+def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, tuning=None, lookahead=True, graded=False):
     """One n x n slab per GPU of an n x (n * world) channel of height `world` (same cells, same cell
     size on every rank: weak scaling); world = 1 is the single-GPU workload of SURVEY.md 8(d).
     --strong calls this with world = 1 under an initialised process group: the n x n channel itself is
@@ -76,7 +104,11 @@ def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, t
     from cfd_amd.solver import StepControl, configure_device
     from cfd_amd.workloads import channel_forced_config, perturbed_parabola_rows
 
-    cfg, mp = channel_forced_config(n, turbulent, max_iter, tol, nj=n * world, length_j=float(world))
+    ratio_j = 1.0
+    if graded:
+        from cfd_amd.workloads import wall_graded_ratio
+        ratio_j = wall_graded_ratio(n * world, 20.0)
+    cfg, mp = channel_forced_config(n, turbulent, max_iter, tol, nj=n * world, length_j=float(world), ratio_j=ratio_j)
     if tuning:
         cfg["solver"]["tuning"] = dict(tuning)
     if not lookahead:
@@ -213,6 +245,9 @@ def main():
     ap.add_argument("--size", type=int, default=8192, help="cells per side of the channel (strong scaling: of the whole "
                     "channel, split over the GPUs; --weak: per GPU)")
     ap.add_argument("--turbulent", action="store_true", help="k-omega variant of the workload")
+    ap.add_argument("--mesh", default="uniform", choices=("uniform", "graded", "annulus"),
+                    help="SURVEY.md 8(d) mesh variants: uniform channel (BASELINE.json's configuration), wall-graded "
+                         "channel (max / min dy = 20), --size x --size/2 half annulus (r 0.5 .. 20, single GPU)")
     ap.add_argument("--max-iter", type=int, default=2)
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--cpu-size", type=str, default="256,512,1024", help="sizes of the CPU baseline legs")
@@ -275,9 +310,16 @@ def main():
     tuning = None
     if args.tuning:
         tuning = {k: float(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))}
-    dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if (strong or world == 1) else world,
-                                 args.transport, tuning=tuning)
+    if args.mesh == "annulus":
+        if world > 1 or args.turbulent:
+            raise SystemExit("--mesh annulus is a single-GPU laminar workload (cfd_mesh_from_nodes is single-rank)")
+        dev, ctl, cfg = setup_annulus(n, n // 2, args.max_iter, args.tol, local, tuning=tuning)
+    else:
+        dev, ctl, cfg = setup_device(n, args.turbulent, args.max_iter, args.tol, local, 1 if (strong or world == 1) else world,
+                                     args.transport, tuning=tuning, graded=args.mesh == "graded")
     cells_total = n * n if (strong or world == 1) else world * n * n
+    if args.mesh == "annulus":
+        cells_total = n * (n // 2)
     cells_gpu = cells_total // world   # cells one launch on this GPU sweeps
     if args.mg_sweeps is not None or args.mg_omegas is not None:
         nu_s = args.mg_sweeps or 3
@@ -402,9 +444,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.shared_gpu else "synthetic (REHEARSAL: ranks share one GPU, not a measurement)",
-            "config": {"workload": f"synthetic {n}x{n if (strong or world == 1) else n * world} periodic channel with "
-                                   f"pressure-gradient forcing ({'k-omega' if args.turbulent else 'laminar'}), SIMPLE "
-                                   f"max_iter={args.max_iter}, continuity_tol=0, cfl=cfl_diff=0.5, "
+            "config": {"workload": (f"synthetic {n}x{n // 2} half annulus around a cylinder (r 0.5 .. 20, laminar, inlet / "
+                                    f"outlet / symmetry / wall), SIMPLE " if args.mesh == "annulus" else
+                                    f"synthetic {n}x{n if (strong or world == 1) else n * world} periodic channel with "
+                                    f"pressure-gradient forcing ({'k-omega' if args.turbulent else 'laminar'}"
+                                    f"{', wall-graded mesh with max / min dy = 20' if args.mesh == 'graded' else ''}), SIMPLE ")
+                                   + f"max_iter={args.max_iter}, continuity_tol=0, cfl=cfl_diff=0.5, "
                                    f"dt_max={cfg['time']['dt_max']:.3g}, rtol={args.tol:g}",
                        "cells_per_gpu": cells_gpu,
                        "parallelism": par + ("" if world == 1 else
