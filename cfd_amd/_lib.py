@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("CFD_HIP_LIB", _HERE / "libcfd_hip.so"))
 
 F_U, F_V, F_P, F_K, F_OMEGA, F_NUT, F_PCORR, F_AP, F_AI, F_AJ, F_BU, F_BV = range(12)
 F_SST_S, F_SST_F1, F_SST_F2, F_SST_DK, F_SST_DW, F_SST_DWALL = range(12, 18)
+F_U_PREV, F_V_PREV, F_P_PREV = 18, 19, 20       # snapshot planes (u_prev, v_prev, p_prev of correct_velocity)
 TURB_KOMEGA, TURB_SST = 0, 1
 KIND_GHOSTED, KIND_CELL, KIND_FACE_I, KIND_FACE_J = range(4)
 RCCL_ID_BYTES = 128     # CFD_RCCL_ID_BYTES of include/cfd_hip.h
@@ -99,6 +100,8 @@ SIGNATURES = {
     "cfd_grad": (C.c_int, [_vp, C.c_int, _dp]),
     "cfd_advect": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "cfd_momentum_rhs": (C.c_int, [_vp, C.c_double]),
+    "cfd_momentum_rhs_from": (C.c_int, [_vp, C.c_double, _dp, _dp, _dp, C.c_double, C.c_double]),
+    "cfd_wall_friction": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp]),
     "cfd_momentum_solve": (C.c_int, [_vp, _dp]),
     "cfd_pressure_solve": (C.c_int, [_vp]),
     "cfd_download_pressure_system": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),

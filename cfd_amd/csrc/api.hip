@@ -427,6 +427,9 @@ static double *field_plane(Ctx *c, int id) {
         case CFD_F_SST_DK: return c->sst_Dk;
         case CFD_F_SST_DW: return c->sst_Dw;
         case CFD_F_SST_DWALL: return c->sst_dw;
+        case CFD_F_U_PREV: return c->su;
+        case CFD_F_V_PREV: return c->sv;
+        case CFD_F_P_PREV: return c->sp;
         default: return nullptr;
     }
 }
@@ -610,6 +613,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "fuse_resid") c->fuse_resid = iv ? 1 : 0;
     else if (n == "nt_stores") c->nt_stores = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
+    else if (n == "scalar_nu") { c->scalar_nu = iv ? 1 : 0; c->ap_cached = false; }
     else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
     else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }
     else if (n == "mg_line_omega") { if (!(value > 0.0 && value <= 1.0)) { set_error("mg_line_omega: (0, 1]"); return CFD_E_ARG; } c->mg_line_omega = value; }
@@ -1145,6 +1149,46 @@ int cfd_momentum_rhs(cfd_ctx *ctx, double dt) {
     CTX_MUT(ctx);
     CFD_TRY(ready(c));
     return launch_momentum_rhs(c, dt, c->U(), c->V(), c->P());
+}
+
+int cfd_momentum_rhs_from(cfd_ctx *ctx, double dt, const double *adv_u, const double *adv_v, const double *extra,
+                          double dpdx, double dpdy) {
+    CTX_MUT(ctx);
+    CFD_TRY(ready(c));
+    if (!adv_u || !adv_v || !(dt > 0.0)) { set_error("cfd_momentum_rhs_from: null advective term or dt <= 0"); return CFD_E_ARG; }
+    CFD_TRY(to_device(c, adv_u, c->kry[11], CFD_KIND_CELL));
+    CFD_TRY(to_device(c, adv_v, c->kry[12], CFD_KIND_CELL));
+    if (extra) CFD_TRY(to_device(c, extra, c->kry[13], CFD_KIND_CELL_GHOSTED));
+    return launch_momentum_rhs_given(c, dt, c->kry[11], c->kry[12], extra ? c->kry[13] : nullptr, -dpdx, -dpdy);
+}
+
+int cfd_wall_friction(cfd_ctx *ctx, int side, int lo, int hi, const double *t_hat, const double *dn, const double *seg_len,
+                      double nu, double rho, int use_nu_t, double *tau, double out[2]) {
+    CTX_MUT(ctx);
+    NEED_MESH();
+    const int n = hi - lo + 1;
+    const int limit = (side == CFD_SIDE_IMIN || side == CFD_SIDE_IMAX)
+                          ? (c->comm.nranks > 1 ? c->comm.nj_global : c->g.nj) : c->g.ni;
+    if (side < 0 || side > 3 || lo < 0 || n < 1 || hi >= limit) {
+        set_error("cfd_wall_friction: faces %d..%d outside side %d (0..%d)", lo, hi, side, limit - 1); return CFD_E_ARG;
+    }
+    if (!t_hat || !dn || !seg_len || !out) { set_error("cfd_wall_friction: null array"); return CFD_E_ARG; }
+    if ((size_t)5 * n > c->g.plane_elems()) { set_error("cfd_wall_friction: segment too long for the staging plane"); return CFD_E_ARG; }
+    // device layout in the staging plane: tx[n], ty[n], dn[n], len[n], then tau[n]
+    double *tab = c->stage_a;
+    std::vector<double> h((size_t)4 * n);
+    for (int q = 0; q < n; ++q) {
+        h[q] = t_hat[2 * q]; h[(size_t)n + q] = t_hat[2 * q + 1];
+        h[(size_t)2 * n + q] = dn[q]; h[(size_t)3 * n + q] = seg_len[q];
+    }
+    CFD_HIP(hipMemcpyAsync(tab, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    CFD_TRY(launch_wall_friction(c, side, lo, n, tab, nu, rho, use_nu_t, tab + (size_t)4 * n, out));
+    if (tau) {
+        CFD_HIP(hipMemcpyAsync(tau, tab + (size_t)4 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        CFD_HIP(hipStreamSynchronize(c->stream));
+    }
+    return CFD_OK;
 }
 
 int cfd_momentum_solve(cfd_ctx *ctx, double res[2]) {

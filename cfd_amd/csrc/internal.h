@@ -271,6 +271,7 @@ struct Ctx {
     char *sst_mem = nullptr;
     char *line_mem = nullptr;      // Thomas factor planes of the line-smoothed multigrid levels (own allocation)
     size_t line_mem_bytes = 0;
+    int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
     double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this
     double mg_line_omega = 0.8;
     double *sst_S = nullptr, *sst_F1 = nullptr, *sst_F2 = nullptr, *sst_Dk = nullptr, *sst_Dw = nullptr, *sst_dw = nullptr;
@@ -384,6 +385,12 @@ int pressure_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, 
 int vcycle(Ctx *c, const double *r, double *z);
 int launch_spmv(Ctx *c, const OpDev &op, const double *x, double *y);
 int time_kernel(Ctx *c, int kernel, int reps, double *avg_us);
+
+// stencil.hip: entry points of the per-phase host wrappers
+int launch_momentum_rhs_given(Ctx *c, double dt, const double *advu, const double *advv, const double *extra, double force_u,
+                              double force_v);
+int launch_wall_friction(Ctx *c, int side, int lo, int n, const double *tab_dev, double nu, double rho, int use_nut,
+                         double *tau_dev, double out[2]);
 
 // noalloc.hip: looks up this GPU's copy of the static scratch array (the current device's), once
 int noalloc_prepare_device();

@@ -158,6 +158,17 @@ __global__ void k_diffusion_ap(Geo g, MeshDev m, const double *nut, double nu, d
     if (i >= g.ni || j >= g.nj) return;
     const size_t c = g.cell(i, j);
     const int P = g.pitch;
+    // nut == nullptr: one viscosity for every face, the reference's scalar branch (solver.py:205-207)
+    if (!nut) {
+        const double aw = nu * m.si[c] / m.di[c], ae = nu * m.si[c + 1] / m.di[c + 1];
+        const double as = nu * m.sj[c] / m.dj[c], an = nu * m.sj[c + P] / m.dj[c + P];
+        ai[c] = aw;
+        if (i == g.ni - 1) ai[c + 1] = ae;
+        aj[c] = as;
+        if (j == g.nj - 1) aj[c + P] = an;
+        ap[c] = m.vol[c] * inv_dt + aw + ae + as + an;
+        return;
+    }
     const double nuP = nu + coef * nut[c];
     // west
     double nf = nuP;
@@ -196,7 +207,8 @@ __global__ void k_diffusion_ap(Geo g, MeshDev m, const double *nut, double nu, d
 
 int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap, const double *nu_plane) {
     hipLaunchKernelGGL(k_diffusion_ap, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(),
-                       nu_plane ? nu_plane : c->nut, nu_plane ? 0.0 : c->nu, nu_plane ? 1.0 : nut_coef, 1.0 / dt, ai, aj, ap);
+                       nu_plane ? nu_plane : (c->scalar_nu ? (const double *)nullptr : c->nut), nu_plane ? 0.0 : c->nu,
+                       nu_plane ? 1.0 : nut_coef, 1.0 / dt, ai, aj, ap);
     CFD_HIP(hipGetLastError());
     return CFD_OK;
 }
@@ -929,6 +941,48 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
     return CFD_OK;
 }
 
+// solve_momentum with the caller's advective right-hand sides (solver.py:848-883): adv_u, adv_v are cell planes the
+// caller computed (compute_advective_rhs, solver.py:672-691), extra is an optional second pressure-like ghosted plane
+// (extra_pressure_field, solver.py:871-872).  Same expression order as k_momentum_rhs.
+__global__ void k_momentum_rhs_given(Geo g, MeshDev m, const double *u, const double *v, const double *p, const double *extra,
+                                     const double *advu, const double *advv, const double *ai, const double *aj, double inv_dt,
+                                     double force_u, double force_v, int per_i, int per_j, double *bu, double *bv) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const int P = g.pitch;
+    const size_t c = g.cell(i, j);
+    const double vol = m.vol[c];
+    double gx, gy;
+    green_gauss([p](size_t q) { return p[q]; }, m, c, P, gx, gy);
+    if (extra) {
+        double ex, ey;
+        green_gauss([extra](size_t q) { return extra[q]; }, m, c, P, ex, ey);
+        gx = gx + ex;
+        gy = gy + ey;
+    }
+    const double su = advu[c] - gx + force_u, sv = advv[c] - gy + force_v;
+    double b_u = vol * inv_dt * u[c] + vol * su;
+    double b_v = vol * inv_dt * v[c] + vol * sv;
+    if (!per_i) {
+        if (i == 0) { b_u += ai[c] * u[c - 1]; b_v += ai[c] * v[c - 1]; }
+        if (i == g.ni - 1) { b_u += ai[c + 1] * u[c + 1]; b_v += ai[c + 1] * v[c + 1]; }
+    }
+    if (!per_j) {
+        if (g.blo(j)) { b_u += aj[c] * u[c - P]; b_v += aj[c] * v[c - P]; }
+        if (g.bhi(j)) { b_u += aj[c + P] * u[c + P]; b_v += aj[c + P] * v[c + P]; }
+    }
+    bu[c] = b_u;
+    bv[c] = b_v;
+}
+
+int launch_momentum_rhs_given(Ctx *c, double dt, const double *advu, const double *advv, const double *extra, double force_u,
+                              double force_v) {
+    hipLaunchKernelGGL(k_momentum_rhs_given, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), c->U(), c->V(),
+                       c->P(), extra, advu, advv, c->ai, c->aj, 1.0 / dt, force_u, force_v, c->per_i, c->per_j, c->bu, c->bv);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
 // ----------------------------------------------------------------------------------
 // k / omega right-hand sides (solver.py:1109-1136, turbulence.py:427-444).  The flux uses
 // p_eff = p + 2/3 k and the momentum a_P; boundary terms use the transport conductances.
@@ -1287,6 +1341,67 @@ int launch_weighted_sum(Ctx *c, const double *f, const double *w, double out[2])
     int tx;
     const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
     hipLaunchKernelGGL(k_weighted_sum, dim3(nb), block2d(), 0, c->stream, c->g, f, w, c->partials, tx, tiles);
+    CFD_HIP(hipGetLastError());
+    c->n_red_blocks = nb;
+    CFD_TRY(reduce_finish(c, 2, 0));
+    return read_scalars(c, 0, 2, out);
+}
+
+// ----------------------------------------------------------------------------------
+// wall shear stress along one boundary segment (post_processing.py:646-664): an edge kernel over the faces lo..hi of
+// one side; tab holds, per face, t_hat_x, t_hat_y, dn_safe and the face length (O(n) geometry the host derives from
+// the mesh once).  tau[q] = rho * nu_eff * (u_t(cell) - u_t(ghost)) / (2 dn_safe); partials: sum tau * len, sum len.
+// Slabs: a rank handles the faces it owns (rows [j0, j0 + nj) of an i side; a j side only on the rank that holds it).
+// ----------------------------------------------------------------------------------
+__global__ void k_wall_friction(Geo g, int side, int lo, int n, int j0, const double *u, const double *v, const double *nut,
+                                const double *tab, double nu, double rho, int use_nut, double *tau, double *partials) {
+    const int P = g.pitch;
+    double a = 0.0, b = 0.0;
+    for (int q = blockIdx.x * 256 + threadIdx.y * 64 + threadIdx.x; q < n; q += gridDim.x * 256) {
+        const int idx = lo + q;
+        int i, j;
+        ptrdiff_t dg;
+        bool mine = true;
+        if (side == CFD_SIDE_IMIN || side == CFD_SIDE_IMAX) {
+            j = idx - j0;
+            i = side == CFD_SIDE_IMIN ? 0 : g.ni - 1;
+            dg = side == CFD_SIDE_IMIN ? -1 : 1;
+            mine = j >= 0 && j < g.nj;
+        } else {
+            i = idx;
+            j = side == CFD_SIDE_JMIN ? 0 : g.nj - 1;
+            dg = side == CFD_SIDE_JMIN ? -(ptrdiff_t)P : (ptrdiff_t)P;
+            mine = side == CFD_SIDE_JMIN ? !g.cutlo : !g.cuthi;
+        }
+        double t = 0.0;
+        if (mine) {
+            const size_t c = g.cell(i, j);
+            const double tx = tab[q], ty = tab[n + q], dn = tab[2 * n + q], len = tab[3 * n + q];
+            const double ut_cell = u[c] * tx + v[c] * ty;
+            const double ut_ghost = u[c + dg] * tx + v[c + dg] * ty;
+            const double dudn = (ut_cell - ut_ghost) / (2.0 * dn);
+            const double nu_eff = use_nut ? nu + nut[c] : nu;
+            t = rho * nu_eff * dudn;
+            a += t * len;
+            b += len;
+        }
+        tau[q] = t;
+    }
+    a = block_sum_256(a);
+    b = block_sum_256(b);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        partials[blockIdx.x] = a;
+        partials[MAX_PARTIALS + blockIdx.x] = b;
+    }
+}
+
+// tab_dev: 4 n doubles (device), tau_dev: n doubles (device); out = {sum tau len, sum len} over all slabs
+int launch_wall_friction(Ctx *c, int side, int lo, int n, const double *tab_dev, double nu, double rho, int use_nut,
+                         double *tau_dev, double out[2]) {
+    int nb = (n + 255) / 256;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(k_wall_friction, dim3(nb), block2d(), 0, c->stream, c->g, side, lo, n, c->comm.nranks > 1 ? c->comm.j_offset : 0,
+                       c->U(), c->V(), c->nut, tab_dev, nu, rho, use_nut, tau_dev, c->partials);
     CFD_HIP(hipGetLastError());
     c->n_red_blocks = nb;
     CFD_TRY(reduce_finish(c, 2, 0));

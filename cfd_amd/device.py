@@ -329,6 +329,32 @@ class Device:
     def momentum_rhs(self, dt):
         check(self.lib.cfd_momentum_rhs(self._h, float(dt)))
 
+    def momentum_rhs_from(self, dt, adv_u, adv_v, extra=None, pressure_gradient=(0.0, 0.0)):
+        """b_u, b_v planes from the caller's advective terms (solver.solve_momentum, solver.py:868-883)."""
+        au, av = _f64(adv_u), _f64(adv_v)
+        if au.shape != (self.ni, self.nj) or av.shape != (self.ni, self.nj):
+            raise ValueError(f"advective terms must be {(self.ni, self.nj)} arrays")
+        ex = None
+        if extra is not None:
+            ex = _f64(extra)
+            if ex.shape != (self.ni + 2, self.nj + 2):
+                raise ValueError(f"extra_pressure_field must be a {(self.ni + 2, self.nj + 2)} array")
+        check(self.lib.cfd_momentum_rhs_from(self._h, float(dt), dptr(au), dptr(av), dptr(ex),
+                                             float(pressure_gradient[0]), float(pressure_gradient[1])))
+
+    def wall_friction(self, side, lo, hi, t_hat, dn, seg_len, nu, rho=1.0, use_nu_t=False, want_tau=False):
+        """(sum tau * len, sum len[, tau]) over the faces lo..hi of one side, from the planes in HBM
+        (include/cfd_hip.h: cfd_wall_friction)."""
+        n = int(hi) - int(lo) + 1
+        t, d, ln = _f64(t_hat), _f64(dn), _f64(seg_len)
+        if t.shape != (n, 2) or d.shape != (n,) or ln.shape != (n,):
+            raise ValueError("t_hat (n, 2), dn (n), seg_len (n) must cover the faces lo..hi")
+        tau = np.empty(n) if want_tau else None
+        out = np.zeros(2)
+        check(self.lib.cfd_wall_friction(self._h, int(side), int(lo), int(hi), dptr(t), dptr(d), dptr(ln), float(nu),
+                                         float(rho), int(bool(use_nu_t)), dptr(tau), dptr(out)))
+        return (float(out[0]), float(out[1]), tau) if want_tau else (float(out[0]), float(out[1]))
+
     def momentum_solve(self):
         res = np.zeros(2)
         check(self.lib.cfd_momentum_solve(self._h, dptr(res)))

@@ -1,7 +1,11 @@
 """In-loop wall-friction diagnostic (post_processing.friction_coefficient_array,
-post_processing.py:588-687 with the segment geometry of 103-170).  O(perimeter) host work on
-the boundary rows; the bulk velocity (the only O(Ni*Nj) part) comes from a device reduction
-when run_case passes u_ref.  Plotting is out of scope."""
+post_processing.py:588-687 with the segment geometry of 103-170).
+
+run_case uses WallFriction + friction_coefficient_device: the geometry of the boundary segment (O(perimeter),
+from the mesh, once per run) goes to the GPU as a small table, an edge kernel gathers u, v, nu_t along the wall
+from the planes in HBM and sums tau * length there (cfd_wall_friction), the bulk velocity is a device reduction
+too -- no field is downloaded for the friction log.  friction_coefficient_array keeps the reference's call
+shape for callers that hold the fields on the host.  Plotting is out of scope."""
 from __future__ import annotations
 
 import numpy as np
@@ -86,3 +90,45 @@ def friction_coefficient_array(fields, mesh, boundary, index_range=None, nu=1.0e
     s_face = np.concatenate(([0.0], np.cumsum(seg_len)))[:-1] + 0.5 * seg_len
     return {"cf": float(cf), "tau_avg": float(tau_avg), "bulk_velocity": float(u_ref), "re": re,
             "cf_dpdx": cf_dpdx, "tau": tau, "s": s_face}
+
+
+class WallFriction:
+    """Geometry of one boundary segment for the device-side friction diagnostic (built once per run)."""
+
+    def __init__(self, mesh, boundary, index_range=None):
+        from ._lib import SIDES
+        fc, cell, n_hat, seg_len, inner, _ = _wall_segment(mesh, boundary, index_range)
+        self.side = SIDES[boundary]
+        along = inner[1] - 1 if boundary in ("i_min", "i_max") else inner[0] - 1
+        self.lo, self.hi = int(along[0]), int(along[-1])
+        self.t_hat = np.ascontiguousarray(np.stack((n_hat[:, 1], -n_hat[:, 0]), axis=-1))
+        dn = np.abs(np.sum((fc - cell) * n_hat, axis=-1))
+        self.dn = np.where(dn > 1.0e-12, dn, 1.0e-12)
+        self.seg_len = np.ascontiguousarray(seg_len)
+        self.length = float(np.sum(seg_len))
+        self.s_face = np.concatenate(([0.0], np.cumsum(seg_len)))[:-1] + 0.5 * seg_len
+
+
+def friction_coefficient_device(dev, wall, nu=1.0e-3, rho=1.0, u_ref=None, use_nu_t=False, flow_axis="i",
+                                hydraulic_diameter=None, pressure_gradient=None, want_tau=False):
+    """friction_coefficient_array (post_processing.py:588-687) on the fields a Device holds in HBM.
+    want_tau adds the per-face shear stresses ("tau", "s") to the result, an O(segment) download."""
+    from . import _lib
+    if u_ref is None:
+        u_ref = dev.bulk_velocity(_lib.F_U if flow_axis == "i" else _lib.F_V)
+    if u_ref == 0.0 or not np.isfinite(u_ref):
+        raise ValueError("u_ref must be nonzero for friction coefficient.")
+    got = dev.wall_friction(wall.side, wall.lo, wall.hi, wall.t_hat, wall.dn, wall.seg_len, nu, rho, use_nu_t, want_tau)
+    tau_avg = float(got[0] / wall.length) if wall.length > 0.0 else 0.0
+    cf = 2.0 * tau_avg / (float(rho) * float(u_ref) ** 2)
+    re = None
+    if hydraulic_diameter is not None:
+        re = float(rho) * float(u_ref) * float(hydraulic_diameter) / float(nu)
+    cf_dpdx = None
+    if pressure_gradient is not None and hydraulic_diameter is not None:
+        dp = float(pressure_gradient[0] if flow_axis == "i" else pressure_gradient[1])
+        cf_dpdx = 2.0 * (-dp * float(hydraulic_diameter) / 4.0) / (float(rho) * float(u_ref) ** 2)
+    out = {"cf": float(cf), "tau_avg": tau_avg, "bulk_velocity": float(u_ref), "re": re, "cf_dpdx": cf_dpdx}
+    if want_tau:
+        out["tau"], out["s"] = got[2], wall.s_face
+    return out

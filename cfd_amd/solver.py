@@ -30,12 +30,18 @@ from pathlib import Path
 
 import numpy as np
 
-from . import _lib, post_processing
+from . import post_processing
 from .bc import BoundaryGeometry, BoundaryTables, _normalize_segments
 from .device import Device
 from .mesh import ensure_single_mesh_file, make_mesh
 
 USE_NUMBA = False            # kept for API compatibility (solver.py:21); the HIP kernels replace numba
+
+# the reference's per-phase functions (README.md:196-205), same call shapes, each executed on the GPU
+# (cfd_amd/phases.py); run_case below does not go through them -- its loop keeps every plane in HBM
+from .phases import (advect_scalar, apply_boundary_conditions, compute_adaptive_dt, compute_advective_rhs,  # noqa: E402,F401
+                     continuity_residual, correct_velocity, grad_scalar, solve_momentum, solve_pressure,
+                     update_turbulence)
 
 
 # ------------------------------------------------------------------ mesh / state IO
@@ -468,6 +474,7 @@ def run_case(config):
         step_end = step + ctl.max_steps
         start_wall_time = time_module.perf_counter()
         host_fresh = False
+        wall = None
         while step < step_end:
             step_start = time_module.perf_counter()
             timing = dict.fromkeys(("total", "bc", "adv", "mom", "press", "corr", "cont", "turb", "post", "save"), 0.0)
@@ -485,16 +492,13 @@ def run_case(config):
             if root and cont_res is not None and (residual_log_interval <= 1 or step % residual_log_interval == 0):
                 log_residual(post_dir, case_name, step, time, inner_iter, cont_res, mom_u_l2, mom_v_l2)
             if friction_enabled and (friction_log_interval <= 1 or step % friction_log_interval == 0):
-                dev.download_fields(fields)
-                host_fresh = True
-                u_ref = friction_cfg.get("u_ref")
-                if u_ref is None:
-                    u_ref = dev.bulk_velocity(_lib.F_U if friction_cfg.get("flow_axis", "i") == "i" else _lib.F_V)
-                friction = post_processing.friction_coefficient_array(
-                    fields, mesh, boundary=friction_cfg.get("boundary", "j_min"),
-                    index_range=friction_cfg.get("range"), nu=config["physics"]["nu"],
-                    rho=friction_cfg.get("rho", 1.0), u_ref=u_ref,
-                    use_nu_t=bool(friction_cfg.get("use_nu_t", False)),
+                # edge kernel + device reductions: nothing but a few scalars crosses PCIe (cfd_wall_friction)
+                if wall is None:
+                    wall = post_processing.WallFriction(mesh, friction_cfg.get("boundary", "j_min"),
+                                                        friction_cfg.get("range"))
+                friction = post_processing.friction_coefficient_device(
+                    dev, wall, nu=config["physics"]["nu"], rho=friction_cfg.get("rho", 1.0),
+                    u_ref=friction_cfg.get("u_ref"), use_nu_t=bool(friction_cfg.get("use_nu_t", False)),
                     flow_axis=friction_cfg.get("flow_axis", "i"),
                     hydraulic_diameter=friction_cfg.get("hydraulic_diameter"),
                     pressure_gradient=config["physics"].get("pressure_gradient"))

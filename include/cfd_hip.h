@@ -44,7 +44,9 @@ enum { CFD_F_U = 0, CFD_F_V = 1, CFD_F_P = 2, CFD_F_K = 3, CFD_F_OMEGA = 4, CFD_
        /* Menter SST caches the reference keeps inside `fields` (turbulence.py:447-534, 343-355): _S, _F1, _F2,
         * _D_k, _D_omega, _d_wall; valid ids only after cfd_set_turbulence_model(ctx, CFD_TURB_SST)          */
        CFD_F_SST_S = 12, CFD_F_SST_F1 = 13, CFD_F_SST_F2 = 14, CFD_F_SST_DK = 15, CFD_F_SST_DW = 16, CFD_F_SST_DWALL = 17,
-       CFD_F_COUNT = 18 };
+       /* the snapshot planes of cfd_snapshot (u_prev, v_prev, p_prev of solver.correct_velocity, solver.py:1056-1087) */
+       CFD_F_U_PREV = 18, CFD_F_V_PREV = 19, CFD_F_P_PREV = 20,
+       CFD_F_COUNT = 21 };
 
 /* turbulence closures (turbulence.py:19-62) */
 enum { CFD_TURB_KOMEGA = 0, CFD_TURB_SST = 1 };
@@ -332,6 +334,18 @@ int cfd_advect(cfd_ctx *ctx, int field_id, const double *flux_i, const double *f
 /* advective + pressure-gradient momentum RHS planes b_u, b_v (solver.py:672-691, 868-883,
  * 723-730) for the current fields and the a_P / a_i / a_j planes                           */
 int cfd_momentum_rhs(cfd_ctx *ctx, double dt);
+/* solver.solve_momentum's right-hand sides from the CALLER'S advective terms (solver.py:848-883): adv_u, adv_v are
+ * host (Ni, Nj) arrays (adv_rhs["u"], adv_rhs["v"] interiors), extra an optional host (Ni+2, Nj+2) array whose
+ * gradient is added to grad p (extra_pressure_field, solver.py:871-872), (dpdx, dpdy) = pressure_gradient       */
+int cfd_momentum_rhs_from(cfd_ctx *ctx, double dt, const double *adv_u, const double *adv_v, const double *extra,
+                          double dpdx, double dpdy);
+/* post_processing.friction_coefficient_array's wall shear stress (post_processing.py:646-664) over the faces
+ * lo..hi (inclusive) of one side, from the u, v (and nu_t when use_nu_t) planes in HBM: nothing but O(hi - lo)
+ * numbers crosses PCIe.  t_hat (n, 2), dn (n: |(fc - cc) . n_hat| floored at 1e-12), seg_len (n) are the host's
+ * geometry of those faces (post_processing.py:103-170, 646, 654-655).  tau: optional host array of n shear stresses
+ * (a j-slab rank fills its own faces, zero elsewhere); out = {sum tau * seg_len, sum seg_len} over all ranks.    */
+int cfd_wall_friction(cfd_ctx *ctx, int side, int lo, int hi, const double *t_hat, const double *dn, const double *seg_len,
+                      double nu, double rho, int use_nu_t, double *tau, double out[2]);
 /* solve the two momentum systems for the stored RHS planes (solver.py:785-818, 885-894)     */
 int cfd_momentum_solve(cfd_ctx *ctx, double res[2]);
 /* pressure-correction system (solver.py:904-1053): RHS from the current fields and solve     */
@@ -376,7 +390,9 @@ int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us, double *avg_bytes_p
  * fusions of DESIGN.md section 3), "nt_stores" (-1 auto / 0 / 1: nontemporal stores of the streaming kernels),
  * "march_ls" (rows per segment of the marching kernels, 0 = default), "mg_line" (-1 auto / 0 / 1: alternating line smoother
  * on the anisotropic / no / all levels; with "mg_line_threshold" and "mg_line_omega" it changes the V-cycle, hence
- * iteration counts, not the converged solution).  No counterpart in the reference.     */
+ * iteration counts, not the converged solution); "scalar_nu" (0 / 1: cfd_momentum_diagonal forms the face conductances
+ * from the scalar nu alone, the scalar branch of solver._diffusion_coefficients, solver.py:205-207, for callers of the
+ * per-phase functions that pass a scalar viscosity).  No counterpart in the reference.     */
 int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
 /* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels
  * its run went through: [0] 4-iteration Chebyshev launches with two right-hand sides, [1] with one, [2] 2-iteration

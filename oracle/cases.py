@@ -265,3 +265,22 @@ LARGE_END_TO_END = {
     "inlet_outlet_160x96": (_inout_large, None),
     "couette_piso_160x96": (_couette_large, perturbed_rest),
 }
+
+
+def _periodic_rect_bc(ni, nj, cell):
+    return {
+        "i_min": {"type": "periodic", "range": (0, nj - 1)},
+        "i_max": {"type": "periodic", "range": (0, nj - 1)},
+        "j_min": {"type": "wall", "range": (0, ni - 1)},
+        "j_max": {"type": "symmetry", "range": (0, ni - 1)},
+        "pressure_reference": {"cell": cell, "value": 0.25},
+    }
+
+
+# boundary configurations of the per-function vectors tests/golden/func_<tag>.npz (and phase_<tag>.npz)
+FUNCTION_VECTOR_BCS = {
+    "annulus_12x16": _half_cylinder_bc(12, 16, True),
+    "rect_8x10": _periodic_rect_bc(8, 10, (1, 2)),
+    "annulus_132x24": _half_cylinder_bc(132, 24, True),
+    "rect_136x20": _periodic_rect_bc(136, 20, (70, 3)),
+}

@@ -21,6 +21,7 @@ Three tiers, recorded in every file's `tier` entry:
 Usage:  python oracle/gen_golden.py            (regenerates everything but the SST and the large rows)
         python oracle/gen_golden.py sst        (SST rows: ref_runs/sst_*, e2e_*sst*)
         python oracle/gen_golden.py large      (func_rect_136x20, func_annulus_132x24, e2e_*_64_*, e2e_*_160x96_*)
+        python oracle/gen_golden.py phase      (phase_<tag>.npz: per-phase function outputs on the func_<tag> states)
 """
 from __future__ import annotations
 
@@ -376,8 +377,74 @@ def main_large():
         remove_pyamg_standin()
 
 
+def main_phase():
+    """python oracle/gen_golden.py phase: outputs of the reference's per-phase functions whose results the func_*
+    vectors do not hold yet (solve_momentum, update_turbulence for both closures, the scalar-viscosity branches),
+    on the boundary-conditioned state of func_<tag>.npz.  Written to phase_<tag>.npz (tier C for the k / omega
+    solves, which go through `pyamg.ruge_stuben_solver`, solver.py:1138-1139: harness stand-in, exact solve)."""
+    ref_solver, ref_mesh, ref_bc, ref_turb, ref_post = load_reference()
+    tight = {"tol": 1.0e-13, "maxiter": 2000}
+    for tag, bc_cfg in cases.FUNCTION_VECTOR_BCS.items():
+        with np.load(OUT / f"func_{tag}.npz", allow_pickle=False) as z:
+            g = {k: z[k] for k in z.files}
+        mesh = {k[5:]: v for k, v in g.items() if k.startswith("mesh_")}
+        nu, dt = (float(x) for x in g["params"])
+        state = {k: g[f"bc_{k}"].copy() for k in ("u", "v", "p")}
+        state["k"], state["omega"], state["nu_t"] = g["tbc_k"].copy(), g["tbc_omega"].copy(), g["nu_t"].copy()
+        nu_eff = nu + state["nu_t"][1:-1, 1:-1]
+        out = {}
+
+        # predictor from the caller's advective terms, forcing and the 2/3 k pressure-like term
+        h = {k: v.copy() for k, v in state.items()}
+        adv = ref_solver.compute_advective_rhs(h, mesh, nu_eff, dt, use_rhie_chow=True, p_field=h["p"])
+        out["adv_rhs_u"], out["adv_rhs_v"] = adv["u"], adv["v"]
+        info = ref_solver.solve_momentum(h, mesh, dt, nu_eff, adv, bc_cfg, tight, p_field=h["p"],
+                                         pressure_gradient=(-0.3, 0.1), extra_pressure_field=(2.0 / 3.0) * h["k"])
+        out["mom_u"], out["mom_v"], out["mom_a_p"] = h["u"].copy(), h["v"].copy(), info["a_p_u"]
+        out["mom_l2"] = np.array([info["mom_u_l2"], info["mom_v_l2"]])
+
+        # the scalar-viscosity branches (solver.py:205-207)
+        h = {k: v.copy() for k, v in state.items()}
+        out["a_p_scalar"] = ref_solver._momentum_diagonal(mesh, nu, dt)
+        adv0 = ref_solver.compute_advective_rhs(h, mesh, nu, dt, use_rhie_chow=True)
+        out["adv0_u"], out["adv0_v"], out["adv0_flux_i"], out["adv0_flux_j"] = adv0["u"], adv0["v"], adv0["flux_i"], adv0["flux_j"]
+        out["continuity_scalar"] = np.array(ref_solver.continuity_residual(h, mesh, nu, dt))
+        out["continuity_norc"] = np.array(ref_solver.continuity_residual(h, mesh, nu, dt, use_rhie_chow=False))
+        out["dt_scalar"] = np.array(ref_solver.compute_adaptive_dt(h, mesh, 0.5, 10.0, 0.0, cfl_diff=0.4, nu_eff=nu))
+        out["dt_adv_only"] = np.array(ref_solver.compute_adaptive_dt(h, mesh, 0.5, 10.0))
+        out["dt_clamped"] = np.array(ref_solver.compute_adaptive_dt(h, mesh, 0.5, 1.0e-7, 0.0, cfl_diff=0.4, nu_eff=nu_eff))
+        info0 = ref_solver.solve_momentum(h, mesh, dt, nu, adv0, bc_cfg, tight)
+        out["mom0_u"], out["mom0_v"] = h["u"].copy(), h["v"].copy()
+
+        # pressure correction with the assembled diagonal (no override) and the scalar viscosity
+        # (through the stand-in's exact solve: the reference's ILU-CG does not reach 1e-13 on the seam-asymmetric
+        # operator of rect_136x20, SURVEY.md F6b)
+        install_pyamg_standin()
+        try:
+            h = {k: v.copy() for k, v in state.items()}
+            pc = ref_solver.solve_pressure(h, mesh, dt, nu, bc_cfg, tight)
+            out["p_corr_scalar"] = pc.copy()
+
+            # one transport step of either closure
+            for model in ("k_omega", "sst"):
+                h = {k: v.copy() for k, v in state.items()}
+                cfg = {"enabled": True, "model": model}
+                ref_solver.update_turbulence(h, mesh, cfg, bc_cfg, dt, nu)
+                ref_turb.eddy_viscosity(h, cfg)
+                for key, val in h.items():
+                    if key in ("k", "omega", "nu_t") or key.startswith("_"):
+                        out[f"turb_{model}_{key}"] = np.asarray(val).copy()
+        finally:
+            remove_pyamg_standin()
+        out["tier"] = np.array("C")
+        np.savez_compressed(OUT / f"phase_{tag}.npz", **out)
+        print(f"wrote phase_{tag}.npz", flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sst":
+    if len(sys.argv) > 1 and sys.argv[1] == "phase":
+        main_phase()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sst":
         main_sst()
     elif len(sys.argv) > 1 and sys.argv[1] == "large":
         main_large()
