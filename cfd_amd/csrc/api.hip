@@ -10,6 +10,7 @@
 namespace cfd {
 
 static thread_local char g_err[1024] = "";
+long long g_launches = 0, g_syncs = 0;
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -315,6 +316,7 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     }
     if (hipEventCreate(&c->ev0) != hipSuccess) { c->ev0 = nullptr; set_error("hipEventCreate failed"); return fail(CFD_E_HIP); }
     if (hipEventCreate(&c->ev1) != hipSuccess) { c->ev1 = nullptr; set_error("hipEventCreate failed"); return fail(CFD_E_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_read, hipEventDisableTiming) != hipSuccess) { c->ev_read = nullptr; set_error("hipEventCreate failed"); return fail(CFD_E_HIP); }
     if (hipStreamSynchronize(c->stream) != hipSuccess) { set_error("hipStreamSynchronize failed"); return fail(CFD_E_HIP); }
     *out = h;
     return CFD_OK;
@@ -330,6 +332,7 @@ int cfd_destroy(cfd_ctx *ctx) {
     for (hipEvent_t e : c->probe_e1) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev_read) hipEventDestroy(c->ev_read);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->h_scal) hipHostFree(c->h_scal);
     if (c->own_ws && c->ws) hipFree(c->ws);
@@ -614,10 +617,19 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "nt_stores") c->nt_stores = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
     else if (n == "scalar_nu") { c->scalar_nu = iv ? 1 : 0; c->ap_cached = false; }
+    else if (n == "host_lag") c->host_lag = iv ? 1 : 0;
+    else if (n == "mg_tail") { c->mg_tail = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
     else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }
     else if (n == "mg_line_omega") { if (!(value > 0.0 && value <= 1.0)) { set_error("mg_line_omega: (0, 1]"); return CFD_E_ARG; } c->mg_line_omega = value; }
     else { set_error("cfd_set_option: unknown option '%s'", name); return CFD_E_ARG; }
+    return CFD_OK;
+}
+
+int cfd_host_counters(long long out[2], int reset) {
+    if (!out) return CFD_E_ARG;
+    out[0] = cfd::g_launches; out[1] = cfd::g_syncs;
+    if (reset) cfd::g_launches = cfd::g_syncs = 0;
     return CFD_OK;
 }
 

@@ -79,6 +79,17 @@ struct FlowBCDev {
 
 void set_error(const char *fmt, ...);
 
+// host-side cost counters (cfd_host_counters): kernel launches and blocking stream synchronisations issued by the
+// library in this process -- the two quantities that bound the step time of small meshes and of thin j-slabs
+extern long long g_launches, g_syncs;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                    \
+    do {                                                                               \
+        ++cfd::g_launches;                                                             \
+        kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                   \
+    } while (0)
+#define hipStreamSynchronize(stream) (++cfd::g_syncs, (hipStreamSynchronize)(stream))
+
 #define CFD_HIP(expr)                                                                         \
     do {                                                                                      \
         hipError_t e__ = (expr);                                                              \
@@ -118,7 +129,7 @@ __device__ __forceinline__ void store_stream(double *p, double v, int nt) {
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
-    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_COUNT = 16
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_COUNT = 16
 };
 
 // ------------------------------------------------------------------ multigrid level
@@ -137,6 +148,25 @@ struct Level {
     bool line = false;
     double *lm = nullptr, *linv = nullptr;
     double aniso = 1.0;           // max over the cells of strong / weak coupling (diagnostic, cfd_level_aniso)
+};
+
+// V-cycle tail: the levels small enough to live in the LDS of one workgroup are cycled by ONE launch (k_mg_tail)
+constexpr int TAIL_NT = 1024;                       // threads of that workgroup
+constexpr int TAIL_CPT = 4;                         // cells per thread on the largest tail level
+constexpr int TAIL_MAX_CELLS = TAIL_NT * TAIL_CPT;
+constexpr int TAIL_MAX_LEVELS = 12;
+constexpr int TAIL_LDS_DOUBLES = 20480;             // 160 KiB, what one gfx950 workgroup may declare
+struct TailLevel {
+    const double *ci, *cj, *D;
+    Geo g;
+    int fi, fj;          // coarsening factors towards the next level
+    int off;             // offset of this level's x and b inside the LDS arrays
+};
+struct TailArgs {
+    TailLevel L[TAIL_MAX_LEVELS];
+    int n, total;        // levels, sum of their cells
+    int per_i, per_j, pre, post, coarse_sweeps, nom;
+    double om[4], om_coarse, gamma;
 };
 
 // j-slab communication: callbacks supplied by the host (torch.distributed over RCCL in
@@ -274,6 +304,9 @@ struct Ctx {
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
     double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this
     double mg_line_omega = 0.8;
+    int mg_tail = 1;             // 1: levels that fit one workgroup's LDS are cycled by one launch
+    int tail_lt = -1;            // first level of the tail (-1: none), set when the hierarchy is built
+    TailArgs tail{};
     double *sst_S = nullptr, *sst_F1 = nullptr, *sst_F2 = nullptr, *sst_Dk = nullptr, *sst_Dw = nullptr, *sst_dw = nullptr;
     double *m_xc = nullptr, *m_yc = nullptr;     // cell centres
     double *wp = nullptr, *wi = nullptr, *wj = nullptr;   // omega transport operator (k keeps tp, ti, tj)
@@ -291,6 +324,13 @@ struct Ctx {
     bool timing = false;
     double phase_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // lagged host reads: the copy of a few device scalars is enqueued, the event recorded behind it, more kernels follow;
+    // the host waits for the event only, so the GPU keeps working while the host looks at the numbers
+    hipEvent_t ev_read = nullptr;
+    int host_lag = 1;            // 0: every read is a full stream synchronisation (A-B switch "host_lag")
+    bool cheb_lag_ok = false;    // the last Chebyshev solve needed at least two launches
+    bool dt_host_valid = false;  // h_dt_ahead holds the (globally reduced) minima the last cont pass computed ahead
+    double h_dt_ahead[2] = {0.0, 0.0};
 
     // live kernel probe (bench.py): HIP-event pairs around every launch of one kernel id
     int probe_kernel = -1;
@@ -378,6 +418,9 @@ inline double global_cells(const Ctx *c) {
 int sum_finish(Ctx *c, const double *partials, int nblocks, int nq, double *out);   // + all-reduce over slabs
 int reduce_finish(Ctx *c, int nq, int scal_off);       // partials -> scal[scal_off .. +nq)
 int read_scalars(Ctx *c, int off, int n, double *host);
+int read_scalars_begin(Ctx *c, int off, int n);             // enqueue the copy into h_scal[off ..) and record ev_read
+int read_scalars_end(Ctx *c, int off, int n, double *host); // wait for ev_read only
+int read_scalars2(Ctx *c, int off1, int n1, double *host1, int off2, int n2, double *host2);   // two ranges, one synchronisation
 int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2], int nb,
                         double tol, int maxiter, int *iters, double relres[2], double rms[2]);
 int build_pressure_hierarchy(Ctx *c);

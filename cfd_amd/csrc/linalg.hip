@@ -81,6 +81,26 @@ int read_scalars(Ctx *c, int off, int n, double *host) {
     return CFD_OK;
 }
 
+int read_scalars_begin(Ctx *c, int off, int n) {
+    CFD_HIP(hipMemcpyAsync(c->h_scal + off, c->scal + off, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CFD_HIP(hipEventRecord(c->ev_read, c->stream));
+    return CFD_OK;
+}
+int read_scalars_end(Ctx *c, int off, int n, double *host) {
+    ++g_syncs;       // counted like a stream synchronisation (the host blocks), though the GPU need not drain
+    CFD_HIP(hipEventSynchronize(c->ev_read));
+    for (int q = 0; q < n; ++q) host[q] = c->h_scal[off + q];
+    return CFD_OK;
+}
+int read_scalars2(Ctx *c, int off1, int n1, double *host1, int off2, int n2, double *host2) {
+    CFD_HIP(hipMemcpyAsync(c->h_scal + off1, c->scal + off1, n1 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (n2 > 0) CFD_HIP(hipMemcpyAsync(c->h_scal + off2, c->scal + off2, n2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    for (int q = 0; q < n1; ++q) host1[q] = c->h_scal[off1 + q];
+    for (int q = 0; q < n2; ++q) host2[q] = c->h_scal[off2 + q];
+    return CFD_OK;
+}
+
 struct Tiling {
     int tx, tiles, blocks;
 };
@@ -190,6 +210,8 @@ struct BiScal {
     double rho[2][2], sigma[2], ts[2], tt[2], rr[2];
 };
 constexpr int BI_OFF = 16;   // offset of BiScal inside Ctx::scal (in doubles)
+constexpr int RR_HIST_OFF = 112;     // Ctx::scal slots: |r|^2 of the last PCG iterations (index it & 7)
+constexpr int CHEB_SAVE_OFF = 104;   // Ctx::scal slots: the sums of the first Chebyshev launch of a solve (read one launch later)
 
 __device__ __forceinline__ double safe_div(double a, double b) { return b != 0.0 ? a / b : 0.0; }
 
@@ -584,6 +606,159 @@ __global__ void k_mg_coarsest(OpDev op, const double *b, double omega, int sweep
     }
 }
 
+
+// ------------------------------------------------------------------ V-cycle tail in one workgroup
+// Levels lt .. nl-1 of the hierarchy (at most TAIL_MAX_CELLS cells on the largest) are cycled by a single
+// workgroup: x and b of every tail level stay in LDS, a thread keeps the couplings of its (at most TAIL_CPT)
+// cells of the level being worked on in registers, the phases are separated by workgroup barriers.  Replaces,
+// per V-cycle, two launches per fused level, eight per unfused level and the coarsest-level kernel -- all of them
+// far below the size at which a launch is worth its latency.  Arithmetic: that of k_mg_first / k_mg_jacobi /
+// k_mg_restrict / k_mg_prolong / k_mg_coarsest (same expressions, same order).
+__global__ __launch_bounds__(TAIL_NT) void k_mg_tail(TailArgs a, const double *b0, double *x0) {
+    extern __shared__ double lds[];              // 2 * total + cells of the largest level, sized by the launch
+    double *X = lds, *B = lds + a.total, *T = lds + 2 * a.total;
+    const int tid = threadIdx.x;
+    double cw[TAIL_CPT], ce[TAIL_CPT], cs[TAIL_CPT], cn[TAIL_CPT], dg[TAIL_CPT];
+    int iw[TAIL_CPT], ie[TAIL_CPT], is[TAIL_CPT], in[TAIL_CPT];
+    int ni = 0, nj = 0, n = 0;
+    // couplings and neighbour slots of this thread's cells of level t (boundary couplings without a neighbour: zero)
+    auto load_level = [&](int t) {
+        const TailLevel &L = a.L[t];
+        ni = L.g.ni; nj = L.g.nj; n = ni * nj;
+#pragma unroll
+        for (int q = 0; q < TAIL_CPT; ++q) {
+            const int idx = tid + q * TAIL_NT;
+            cw[q] = ce[q] = cs[q] = cn[q] = 0.0; dg[q] = 0.0;
+            iw[q] = ie[q] = is[q] = in[q] = 0;
+            if (idx < n) {
+                const int i = idx % ni, j = idx / ni;
+                const size_t c = L.g.cell(i, j), P = L.g.pitch;
+                dg[q] = L.D[c];
+                iw[q] = ie[q] = is[q] = in[q] = idx;
+                if (i > 0) { cw[q] = L.ci[c]; iw[q] = idx - 1; }
+                else if (a.per_i) { cw[q] = L.ci[c]; iw[q] = idx + (ni - 1); }
+                if (i < ni - 1) { ce[q] = L.ci[c + 1]; ie[q] = idx + 1; }
+                else if (a.per_i) { ce[q] = L.ci[c + 1]; ie[q] = idx - (ni - 1); }
+                if (j > 0) { cs[q] = L.cj[c]; is[q] = idx - ni; }
+                else if (a.per_j) { cs[q] = L.cj[c]; is[q] = idx + (nj - 1) * ni; }
+                if (j < nj - 1) { cn[q] = L.cj[c + P]; in[q] = idx + ni; }
+                else if (a.per_j) { cn[q] = L.cj[c + P]; in[q] = idx - (nj - 1) * ni; }
+            }
+        }
+    };
+    // (A x) at slot q of the loaded level
+    auto apply = [&](const double *x, int q, int idx) {
+        double s = 0.0;
+        s += cw[q] * x[iw[q]];
+        s += ce[q] * x[ie[q]];
+        s += cs[q] * x[is[q]];
+        s += cn[q] * x[in[q]];
+        return dg[q] * x[idx] - s;
+    };
+    auto first = [&](const double *b, double om, double *x, bool guard) {
+#pragma unroll
+        for (int q = 0; q < TAIL_CPT; ++q) {
+            const int idx = tid + q * TAIL_NT;
+            if (idx < n) x[idx] = (!guard || dg[q] > 0.0) ? om * b[idx] / dg[q] : 0.0;
+        }
+        __syncthreads();
+    };
+    auto jacobi = [&](const double *b, const double *x, double om, double *xn, bool guard) {
+#pragma unroll
+        for (int q = 0; q < TAIL_CPT; ++q) {
+            const int idx = tid + q * TAIL_NT;
+            if (idx < n) {
+                const double ax = apply(x, q, idx);
+                xn[idx] = (!guard || dg[q] > 0.0) ? x[idx] + om * (b[idx] - ax) / dg[q] : 0.0;
+            }
+        }
+        __syncthreads();
+    };
+    const int nt = a.n;
+    // right-hand side of the first tail level: from its plane in global memory
+    {
+        const TailLevel &L = a.L[0];
+        const int n0 = L.g.ni * L.g.nj;
+        for (int idx = tid; idx < n0; idx += TAIL_NT) B[idx] = b0[L.g.cell(idx % L.g.ni, idx / L.g.ni)];
+        __syncthreads();
+    }
+    // ---- down: pre-smoothing from a zero guess, residual, restriction
+    for (int t = 0; t < nt - 1; ++t) {
+        load_level(t);
+        double *xt = X + a.L[t].off, *bt = B + a.L[t].off;
+        // the pre-smoothed x must end in xt: start in xt for an odd number of sweeps, in T otherwise
+        double *cur = (a.pre & 1) ? xt : T, *oth = (a.pre & 1) ? T : xt;
+        first(bt, a.om[0], cur, false);
+        for (int s = 1; s < a.pre; ++s) {
+            jacobi(bt, cur, a.om[s % a.nom], oth, false);
+            double *tmp = cur; cur = oth; oth = tmp;
+        }
+        // residual into T, then one thread per coarse cell sums its aggregate
+#pragma unroll
+        for (int q = 0; q < TAIL_CPT; ++q) {
+            const int idx = tid + q * TAIL_NT;
+            if (idx < n) T[idx] = bt[idx] - apply(xt, q, idx);
+        }
+        __syncthreads();
+        const TailLevel &C = a.L[t + 1];
+        const int fi = a.L[t].fi, fj = a.L[t].fj, nic = C.g.ni, nc = C.g.ni * C.g.nj;
+        double *bc = B + C.off;
+        for (int idc = tid; idc < nc; idc += TAIL_NT) {
+            const int i = idc % nic, j = idc / nic;
+            double s = 0.0;
+            for (int dj = 0; dj < fj; ++dj) {
+                const int jf = j * fj + dj;
+                if (jf >= nj) break;
+                for (int di = 0; di < fi; ++di) {
+                    const int ifn = i * fi + di;
+                    if (ifn >= ni) break;
+                    s += T[jf * ni + ifn];
+                }
+            }
+            bc[idc] = s;
+        }
+        __syncthreads();
+    }
+    // ---- coarsest level: many damped sweeps from zero
+    const double *e;
+    {
+        const int t = nt - 1;
+        load_level(t);
+        double *xt = X + a.L[t].off, *bt = B + a.L[t].off;
+        double *cur = xt, *oth = T;
+        first(bt, a.om_coarse, cur, true);
+        const int sweeps = nt == 1 ? a.coarse_sweeps : a.coarse_sweeps;
+        for (int s = 1; s < sweeps; ++s) {
+            jacobi(bt, cur, a.om_coarse, oth, true);
+            double *tmp = cur; cur = oth; oth = tmp;
+        }
+        e = cur;
+    }
+    // ---- up: prolongation, post-smoothing
+    for (int t = nt - 2; t >= 0; --t) {
+        const int nic = a.L[t + 1].g.ni, fi = a.L[t].fi, fj = a.L[t].fj;
+        load_level(t);
+        double *xt = X + a.L[t].off, *bt = B + a.L[t].off;
+#pragma unroll
+        for (int q = 0; q < TAIL_CPT; ++q) {
+            const int idx = tid + q * TAIL_NT;
+            if (idx < n) xt[idx] += a.gamma * e[((idx / ni) / fj) * nic + (idx % ni) / fi];
+        }
+        __syncthreads();
+        double *cur = xt, *oth = T;
+        for (int s = 0; s < a.post; ++s) {
+            jacobi(bt, cur, a.om[s % a.nom], oth, false);
+            double *tmp = cur; cur = oth; oth = tmp;
+        }
+        e = cur;
+    }
+    // ---- result of the first tail level back to its plane
+    {
+        const TailLevel &L = a.L[0];
+        const int n0 = L.g.ni * L.g.nj;
+        for (int idx = tid; idx < n0; idx += TAIL_NT) x0[L.g.cell(idx % L.g.ni, idx / L.g.ni)] = e[idx];
+    }
+}
 
 // ------------------------------------------------------------------ fused marching multigrid kernels
 // One wavefront owns a column strip: lane = column, it marches down the rows of a segment.
@@ -1683,6 +1858,8 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         kdone[q] = k;
         return CFD_OK;
     };
+    const bool lag = c->host_lag && c->cheb_lag_ok;
+    bool first_pending = false;
     for (int m = 1;; ++m) {
         int qs[2], na = 0;
         for (int q = 0; q < NB; ++q)
@@ -1734,18 +1911,47 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         c->probe_end(probe_id, 8.0 * (3 + (5 - (m == 1 ? 1 : 0)) * na));
         c->kc[K == 4 ? (na == 2 ? KC_CHEB4_2RHS : KC_CHEB4_1RHS) : KC_CHEB2] += 1;
         CFD_HIP(hipGetLastError());
-        const int k0 = K * (m - 1);                // this launch measured |r_k0| and |r_{k0+K-1}|
+        int k0 = K * (m - 1);                      // this launch measured |r_k0| and |r_{k0+K-1}|
+        // The sums of the first launch (|r_0|, |b|: how many iterations to expect) are looked at one launch later
+        // when the previous solve needed a second launch too: the copy is enqueued behind launch 1, the host waits
+        // for it only after launch 2 is in the queue, so the GPU does not idle while the host decides.
+        if (m == 1 && lag) {
+            CFD_TRY(sum_finish(c, c->partials, (int)grid.x, 3 * na, c->scal + CHEB_SAVE_OFF));
+            CFD_TRY(read_scalars_begin(c, CHEB_SAVE_OFF, 3 * na));
+            first_pending = true;
+            continue;
+        }
         int kmin = 1 << 30;
         for (int t = 0; t < na; ++t) kmin = std::min(kmin, kq[qs[t]]);
-        if (m == 1 || k0 + K - 1 >= kmin || k0 + K - 1 >= klimit) {
+        const int n_pass = first_pending ? 2 : 1;
+        for (int pass = 0; pass < n_pass; ++pass) {
+          const bool late_first = first_pending;         // pass 0 of two: the data of launch 1, read now
+          const int mm = late_first ? 1 : m;
+          if (late_first) k0 = 0; else k0 = K * (m - 1);
+          if (!late_first) {
+              kmin = 1 << 30;
+              for (int t = 0; t < na; ++t) if (act[qs[t]]) kmin = std::min(kmin, kq[qs[t]]);
+          }
+          if (late_first || mm == 1 || k0 + K - 1 >= kmin || k0 + K - 1 >= klimit) {
             // partial sums of a launch with na right-hand sides: [t] = |r_k0|^2, [na + t] = |r_{k0+K-1}|^2, [2 na + t] = |b|^2
-            const int nq = m == 1 ? 3 * na : 2 * na;
-            CFD_TRY(sum_finish(c, c->partials, (int)grid.x, nq, c->scal));
+            const int nq = mm == 1 ? 3 * na : 2 * na;
             double got[6];
-            CFD_TRY(read_scalars(c, 0, nq, got));
+            if (late_first) {
+                CFD_TRY(read_scalars_end(c, CHEB_SAVE_OFF, nq, got));
+                first_pending = false;
+            } else {
+                CFD_TRY(sum_finish(c, c->partials, (int)grid.x, nq, c->scal));
+                CFD_TRY(read_scalars(c, 0, nq, got));
+            }
             for (int q = 0; q < nq; ++q)
                 if (!(got[q] == got[q])) { set_error("Chebyshev: non-finite residual near iteration %d", k0); return CFD_E_NUMERIC; }
-            if (m == 1) {
+            // iterates a retiring right-hand side is taken from: those of the launch whose sums these are
+            double *it_k0[2], *it_last[2];
+            for (int q = 0; q < NB; ++q) {
+                it_k0[q] = late_first ? const_cast<double *>(x0[q]) : cur_k[q];
+                it_last[q] = late_first ? set[1][0][q] : set[m & 1][0][q];
+            }
+            if (mm == 1) {
                 bool all_done = true;
                 int kmax = 1;
                 for (int q = 0; q < NB; ++q) {
@@ -1761,14 +1967,17 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             }
             for (int t = 0; t < na; ++t) {
                 const int q = qs[t];
-                if (conv(q, got[t])) CFD_TRY(retire(q, k0, got[t], cur_k[q]));
-                else if (conv(q, got[na + t])) CFD_TRY(retire(q, k0 + K - 1, got[na + t], set[m & 1][0][q]));
+                if (!act[q]) continue;               // retired by the late look at launch 1
+                if (conv(q, got[t])) CFD_TRY(retire(q, k0, got[t], it_k0[q]));
+                else if (conv(q, got[na + t])) CFD_TRY(retire(q, k0 + K - 1, got[na + t], it_last[q]));
             }
             if (!act[0] && !act[NB - 1]) {
                 *iters = std::max(kdone[0], kdone[NB - 1]);
                 *used = 1;
+                c->cheb_lag_ok = m >= 2 && !late_first;
                 return CFD_OK;
             }
+            if (late_first) continue;                // now the sums of launch 2 itself, if it is time for them
             if (k0 + K - 1 >= klimit) {
                 // bound not met (spectrum outside the interval): hand the newest iterate to BiCGStab
                 for (int q = 0; q < NB; ++q)
@@ -1778,6 +1987,7 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                 *iters = k0 + K;
                 return CFD_OK;
             }
+          }
         }
     }
 }
@@ -2122,6 +2332,38 @@ int build_pressure_hierarchy(Ctx *c) {
         }
         if (n_line > c->kc[KC_MG_LINE_LEVELS_MAX]) c->kc[KC_MG_LINE_LEVELS_MAX] = n_line;
     }
+    // ---- V-cycle tail: the first level from which everything below fits the LDS of one workgroup (replicated
+    // levels only on j-slabs; point-smoothed levels only)
+    c->tail_lt = -1;
+    {
+        const int nl = (int)c->levels.size();
+        int last_line = -1;
+        for (int l = 0; l < nl; ++l)
+            if (c->levels[l].line) last_line = l;
+        if (c->mg_tail && nl > 1) {
+            for (int lt = std::max(1, std::max(la, last_line + 1)); lt < nl; ++lt) {
+                long total = 0;
+                for (int l = lt; l < nl; ++l) total += (long)c->levels[l].g.ni * c->levels[l].g.nj;
+                const long top = (long)c->levels[lt].g.ni * c->levels[lt].g.nj;
+                if (top > TAIL_MAX_CELLS || nl - lt > TAIL_MAX_LEVELS || 2 * total + top > TAIL_LDS_DOUBLES) continue;
+                TailArgs &a = c->tail;
+                a = TailArgs{};
+                a.n = nl - lt;
+                a.total = (int)total;
+                int off = 0;
+                for (int l = lt; l < nl; ++l) {
+                    const Level &L = c->levels[l];
+                    TailLevel &t = a.L[l - lt];
+                    t.ci = L.ci; t.cj = L.cj; t.D = L.D; t.g = L.g; t.off = off;
+                    t.fi = t.fj = 1;
+                    if (l + 1 < nl) factors(L.g, c->levels[l + 1].g, t.fi, t.fj);
+                    off += L.g.ni * L.g.nj;
+                }
+                c->tail_lt = lt;
+                break;
+            }
+        }
+    }
     c->p_built = true;
     return CFD_OK;
 }
@@ -2187,7 +2429,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     std::vector<char> rhs_sent(nl, 0), x_sent(nl, 0);
     c->kc[KC_VCYCLE] += 1;
     int n_fused_levels = 0;
-    for (int l = 0; l < nl - 1; ++l) {
+    const int lt = c->tail_lt;                   // levels [lt, nl) are cycled by k_mg_tail in one launch
+    const int n_top = lt > 0 ? lt : nl - 1;      // levels [0, n_top) run their own kernels
+    for (int l = 0; l < n_top; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
         const OpDev op = level_op(c, L);
@@ -2258,7 +2502,23 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         }
         if (to_agg) CFD_TRY(all_gather_rows(c, cb + NG * (size_t)cg.pitch, C.b + NG * (size_t)cg.pitch, (size_t)cg.nj * cg.pitch));
     }
-    {
+    if (lt > 0) {
+        TailArgs a = c->tail;
+        a.per_i = c->pp_per_i; a.per_j = c->pp_per_j; a.pre = pre; a.post = post; a.coarse_sweeps = c->mg_coarse_sweeps;
+        a.nom = c->mg_nom < 4 ? c->mg_nom : 4;
+        for (int q = 0; q < a.nom; ++q) a.om[q] = c->om_at(q);
+        a.om_coarse = c->om_mean(); a.gamma = c->mg_gamma;
+        const size_t lds_bytes = (2 * (size_t)a.total + (size_t)a.L[0].g.ni * a.L[0].g.nj) * sizeof(double);
+        static bool lds_limit_raised = false;
+        if (!lds_limit_raised) {
+            CFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mg_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        TAIL_LDS_DOUBLES * (int)sizeof(double)));
+            lds_limit_raised = true;
+        }
+        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(TAIL_NT), lds_bytes, st, a, rhs[lt], cur[lt]);
+        CFD_HIP(hipGetLastError());
+        if (nl - lt > c->kc[KC_MG_TAIL_LEVELS]) c->kc[KC_MG_TAIL_LEVELS] = nl - lt;
+    } else {
         const Level &L = c->levels[nl - 1];
         const OpDev op = level_op(c, L);
         if (nl == 1) {
@@ -2279,7 +2539,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         CFD_HIP(hipGetLastError());
     }
     *dot_blocks = 0;
-    for (int l = nl - 2; l >= 0; --l) {
+    for (int l = n_top - 1; l >= 0; --l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
         const OpDev op = level_op(c, L);
@@ -2555,22 +2815,30 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     }
     CFD_HIP(hipGetLastError());
     CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(bb)));
-    double bb, rr;
-    CFD_TRY(read_scalars(c, CG_OFF_OF(bb), 1, &bb));
-    if (!(bb == bb)) { set_error("pressure solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
+    double bb = -1.0, rr = 0.0;
     *iters = 0;
     *relres = 0.0;
-    if (bb == 0.0) {
-        if (fused) CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
-        if (c->p_ns_active && c->pin_value != 0.0) {
-            CFD_TRY(ns_shift_scalar(c, S, 0, 0, 1, x, x));
-            hipLaunchKernelGGL(k_add_scalar, grid, blk, 0, st, g, T, c->scal + 81, x);
-            CFD_HIP(hipGetLastError());
+    // |b|^2 is looked at when the first residual is: with an iteration count to expect (a previous solve with this
+    // operator) the host does not stop the GPU for it.  A zero right-hand side then runs through the iterations
+    // with alpha = beta = 0 (safe_div) and leaves x = 0.
+    const bool lazy_bb = c->host_lag && c->p_iters_hint > 0;
+    if (!lazy_bb) {
+        CFD_TRY(read_scalars(c, CG_OFF_OF(bb), 1, &bb));
+        if (!(bb == bb)) { set_error("pressure solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
+        if (bb == 0.0) {
+            if (fused) CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
+            if (c->p_ns_active && c->pin_value != 0.0) {
+                CFD_TRY(ns_shift_scalar(c, S, 0, 0, 1, x, x));
+                hipLaunchKernelGGL(k_add_scalar, grid, blk, 0, st, g, T, c->scal + 81, x);
+                CFD_HIP(hipGetLastError());
+            }
+            return CFD_OK;
         }
-        return CFD_OK;
+        rr = bb;
     }
-    rr = bb;
     int it = 0;
+    const int hint0 = c->p_iters_hint;
+    int converged_at = -1;
     // Iterations whose |r| the host does not look at leave r = r - alpha q to the pre-smoother of the next V-cycle
     // (k_mg_down_k<true, 3, true>): r ping-pongs between the right-hand side plane and kry[1].  Needs the three-sweep
     // marching kernels on the finest level; on j-slabs q crosses the cuts in place of r.
@@ -2631,17 +2899,37 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         }
         CFD_HIP(hipGetLastError());
         ++it;
-        // The host looks at |r| (one stream synchronisation, during which the GPU idles) only from two
-        // iterations before the count the previous solve with this frozen operator needed; the stopping
-        // test itself is unchanged.  Iterations that are not looked at leave their partial sums of (r, r)
-        // unreduced (one small kernel and, on j-slabs, one all-reduce less).
+        // The host looks at |r| (one stream synchronisation, during which the GPU idles) first at the count the
+        // previous solve with this frozen operator needed.  The two iterations before it leave their |r|^2 in
+        // device slots that the same read brings along: had one of them met the test already, the next solve
+        // expects that count (this one has then iterated one or two times more than it had to; the stopping
+        // test itself is unchanged).  Earlier iterations leave their partial sums of (r, r) unreduced (one small
+        // kernel and, on j-slabs, one all-reduce less).
+        if (c->host_lag) {
+            if (it + 2 < hint0 && it < maxiter) continue;
+            CFD_TRY(finish_to(c, T.blocks, 1, RR_HIST_OFF + (it & 7)));
+            if (it < hint0 && it < maxiter) continue;
+            double hist[8];
+            CFD_TRY(read_scalars2(c, RR_HIST_OFF, 8, hist, CG_OFF_OF(bb), bb < 0.0 ? 1 : 0, &bb));
+            if (!(bb == bb)) { set_error("pressure solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
+            rr = hist[it & 7];
+            if (!(rr == rr)) { set_error("PCG: non-finite residual at iteration %d", it); return CFD_E_NUMERIC; }
+            if (sqrt(rr) <= tol * sqrt(bb)) {
+                converged_at = it;
+                if (it == hint0)
+                    for (int k = it - 1; k >= 1 && k + 2 >= hint0; --k)
+                        if (sqrt(hist[k & 7]) <= tol * sqrt(bb)) converged_at = k;
+                break;
+            }
+            continue;
+        }
         if (it + 2 < c->p_iters_hint && it < maxiter) continue;
         CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rr)));
         CFD_TRY(read_scalars(c, CG_OFF_OF(rr), 1, &rr));
         if (!(rr == rr)) { set_error("PCG: non-finite residual at iteration %d", it); return CFD_E_NUMERIC; }
         if (sqrt(rr) <= tol * sqrt(bb)) break;
     }
-    c->p_iters_hint = it;
+    c->p_iters_hint = converged_at > 0 ? converged_at : it;
     if (fused && it > 0) {
         if (c->p_ns_active) CFD_TRY(ns_shift_scalar(c, S, (it - 1) & 1, 1, it == 1, p, x));
         hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, it == 1, p,
@@ -2656,7 +2944,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         }
     }
     *iters = it;
-    *relres = sqrt(rr / bb);
+    *relres = bb > 0.0 ? sqrt(rr / bb) : 0.0;
     return CFD_OK;
 }
 

@@ -812,6 +812,20 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
             CFD_HIP(hipGetLastError());
             CFD_HIP(hipMemcpyAsync(c->scal + DT_AHEAD_OFF + 1, c->scal + 1, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         }
+        if (c->dt_host_valid && !(use_cfl_diff && !c->dt_ahead_diff)) {
+            // already on the host (read together with the continuity residual of the pass that computed them)
+            c->dt_host_valid = false;
+            out[0] = c->h_dt_ahead[0]; out[1] = c->h_dt_ahead[1];
+            return CFD_OK;
+        }
+        if (c->dt_host_valid) {
+            // the advective minimum is on the host and reduced already; the diffusive one was just recomputed
+            c->dt_host_valid = false;
+            CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF + 1, 1, 1));
+            CFD_TRY(read_scalars(c, DT_AHEAD_OFF + 1, 1, out + 1));
+            out[0] = c->h_dt_ahead[0];
+            return CFD_OK;
+        }
         CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF, 2, 1));
         return read_scalars(c, DT_AHEAD_OFF, 2, out);
     }
@@ -839,11 +853,20 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
     return read_scalars(c, 0, 2, out);
 }
 
-static int finish_continuity(Ctx *c, int nb, double *out) {
+// with_dt: the pass also left the time-step minima of these fields in scal[DT_AHEAD_OFF ..): the same
+// synchronisation brings them to the host, so the next cfd_compute_dt call costs none
+static int finish_continuity(Ctx *c, int nb, double *out, bool with_dt = false) {
     c->n_red_blocks = nb;
     CFD_TRY(reduce_finish(c, 1, 0));
     double s;
-    CFD_TRY(read_scalars(c, 0, 1, &s));
+    c->dt_host_valid = false;
+    if (with_dt && c->host_lag) {
+        CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF, 2, 1));       // global minimum over the slabs
+        CFD_TRY(read_scalars2(c, 0, 1, &s, DT_AHEAD_OFF, 2, c->h_dt_ahead));
+        c->dt_host_valid = true;
+    } else {
+        CFD_TRY(read_scalars(c, 0, 1, &s));
+    }
     *out = sqrt(s / global_cells(c));
     return CFD_OK;
 }
@@ -929,7 +952,7 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
                                (double *)nullptr, c->partials);
         }
         CFD_HIP(hipGetLastError());
-        if (cont) return finish_continuity(c, fm.blocks, cont);
+        if (cont) return finish_continuity(c, fm.blocks, cont, dt_too);
         return CFD_OK;
     }
     c->kc[KC_FLUX_TILE] += 1;

@@ -431,13 +431,19 @@ class Device:
 
     KERNEL_COUNT_NAMES = ("cheb4_2rhs", "cheb4_1rhs", "cheb2", "cheb1", "bicgstab_iters", "flux_march",
                           "flux_march_multistrip", "flux_tile", "mg_fused_levels_max", "mg_deferred_resid", "cg_pq",
-                          "vcycles", "mg_line_levels_max")
+                          "vcycles", "mg_line_levels_max", "mg_tail_levels")
 
     def kernel_counts(self, reset=False):
         """Launches per kernel family since the last reset (include/cfd_hip.h: cfd_kernel_counts)."""
         out = (C.c_longlong * 16)()
         check(self.lib.cfd_kernel_counts(self._h, out, 16, int(reset)))
         return dict(zip(self.KERNEL_COUNT_NAMES, [int(v) for v in out]))
+
+    def host_counters(self, reset=False):
+        """(kernel launches, blocking stream synchronisations) of the library in this process so far."""
+        out = (C.c_longlong * 2)()
+        check(self.lib.cfd_host_counters(out, int(reset)))
+        return int(out[0]), int(out[1])
 
     def enable_phase_timing(self, on=True):
         check(self.lib.cfd_enable_phase_timing(self._h, int(on)))

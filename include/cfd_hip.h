@@ -401,6 +401,10 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
  * iterations whose residual update ran inside the pre-smoother, [10] fused PCG direction steps, [11] V-cycles,
  * [12] max number of levels smoothed by j-lines.  n <= 16 entries are written.  No counterpart in the reference.  */
 int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset);
+/* Host-side cost of the calls so far, process wide: out[0] = kernel launches, out[1] = blocking stream
+ * synchronisations the library issued (each one idles the GPU while the host reads a scalar).  They bound the step
+ * time of small meshes and thin j-slabs (tools/small_mesh_timing.py).  No counterpart in the reference.            */
+int cfd_host_counters(long long out[2], int reset);
 /* accumulated device time per phase since the last reset (HIP events), microseconds:
  * {bc, adv(rhs), mom, press, corr, cont, turb, dt}                                          */
 int cfd_phase_times(cfd_ctx *ctx, double out[8], int reset);

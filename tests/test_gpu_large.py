@@ -73,18 +73,25 @@ def _compare(g, fields, step, time, log):
     assert np.all(np.abs(log[:, 1] - h[:, 1]) <= 2e-6 * np.maximum(h[:, 1], 1e-30) + 1e-300)
 
 
+@pytest.mark.parametrize("tail", [1, 0])
 @pytest.mark.parametrize("name", list(cases.LARGE_END_TO_END))
-def test_production_kernels_against_reference(name, tmp_path):
-    """run_case on the GPU vs the reference (golden vectors) after 3 outer steps, and proof of the kernel path."""
+def test_production_kernels_against_reference(name, tail, tmp_path):
+    """run_case on the GPU vs the reference (golden vectors) after 3 outer steps, and proof of the kernel path.
+    tail = 1 (default): the levels below 4096 cells are cycled by k_mg_tail in one launch; tail = 0: every level
+    runs its own kernels, as the levels above the tail do at 8192^2."""
     g = load_golden(f"e2e_{name}_frozen.npz")
-    fields, step, time, log, last, cfg, mesh = _run(name, tmp_path)
+    fields, step, time, log, last, cfg, mesh = _run(name, tmp_path, tuning={"mg_tail": tail})
     _compare(g, fields, step, time, log)
     kc = last["kernel_counts"]
     big = "160x96" in name
     # marching flux kernels; more than one 62-column strip on every mesh of this file
     assert kc["flux_march"] > 0 and kc["flux_march_multistrip"] == kc["flux_march"] and kc["flux_tile"] == 0, kc
-    # fused V-cycle levels: 64x64 -> 32x32 -> 16x16 (-> 8x8 unfused): 3; 160x96 -> 80x48 -> 40x24 (-> 20x12): 3
-    assert kc["mg_fused_levels_max"] >= 3, kc
+    if tail:
+        # 64x64 | 32x32 -> 16x16 -> 8x8 -> 4x4;  160x96 | 80x48 -> 40x24 -> 20x12 -> 10x6 -> 5x3
+        assert kc["mg_fused_levels_max"] >= 1 and kc["mg_tail_levels"] >= 4, kc
+    else:
+        # fused V-cycle levels: 64x64 -> 32x32 -> 16x16 (-> 8x8 unfused): 3; 160x96 -> 80x48 -> 40x24 (-> 20x12): 3
+        assert kc["mg_fused_levels_max"] >= 3 and kc["mg_tail_levels"] == 0, kc
     assert kc["cg_pq"] > 0 and kc["mg_deferred_resid"] > 0, kc       # PCG with residual updates inside the pre-smoother
     if "couette" not in name:
         # CFL-limited steps: the momentum (and k / omega) solves are 4-iteration Chebyshev launches, with both
@@ -119,7 +126,7 @@ def test_production_kernels_against_oracle(name, tmp_path):
     fixup(cfg2, mesh2)
     cfg2["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
     cfg2["solver"]["momentum"]["tol"] = TRANSPORT_TOL
-    cfg2["solver"]["tuning"] = {"mg_line": 0}
+    cfg2["solver"]["tuning"] = {"mg_line": 0, "mg_tail": 0}
     fields, step, time = hip_solver.run_case(cfg2)
     assert step == rstep == 5 and abs(time - rtime) <= 1e-11 * rtime
     unorm = np.linalg.norm(ref["u"].ravel())

@@ -16,6 +16,7 @@ for n, turb in ((32, False), (64, False), (128, False), (256, False), (512, Fals
         advance_one_step(dev, ctl, step)
         step += 1
     dev.synchronize()
+    dev.host_counters(reset=True)
     t0 = time.perf_counter()
     k = 20
     for _ in range(k):
@@ -23,7 +24,9 @@ for n, turb in ((32, False), (64, False), (128, False), (256, False), (512, Fals
         step += 1
     dev.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / k
+    launches, syncs = dev.host_counters()
     st = dev.stats()
     print(json.dumps({"n": n, "turbulent": turb, "ms_per_step": round(ms, 3), "cells_per_s": round(n * n / ms * 1e3),
+                      "launches_per_step": round(launches / k, 1), "syncs_per_step": round((syncs - 1) / k, 1),
                       "mom_iters": st["mom_iters"], "p_iters": st["p_iters"], "k_iters": st["k_iters"]}), flush=True)
     dev.close()
