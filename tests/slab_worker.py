@@ -30,6 +30,7 @@ def build_case(name, work):
         "channel_sst_48x64": (lambda: cases.channel_forced(n=64, steps=3, turbulent=True, ratio_j=1.03, model="sst"), cases.perturbed_parabola, {"count_i": 48}),
         "half_cylinder_sst_24x32": (lambda: cases.half_cylinder(nr=24, nt=32, steps=3, turbulent=True, model="sst"), None, {}),
         "channel_lam_64x128": (lambda: cases.channel_forced(n=64, steps=2, ratio_j=1.0), cases.perturbed_parabola, {"count_j": 128}),
+        "channel_lam_64x256": (lambda: cases.channel_forced(n=64, steps=2, ratio_j=1.0), cases.perturbed_parabola, {"count_j": 256}),
         "inlet_outlet_40x32": (lambda: cases.inlet_outlet_channel(ni=40, nj=32, steps=4), None, {}),
         "couette_piso_24x32": (lambda: cases.couette_piso(ni=24, nj=32, steps=4), cases.perturbed_rest, {}),
         "half_cylinder_komega_24x32": (lambda: cases.half_cylinder(nr=24, nt=32, steps=3, turbulent=True), None, {}),

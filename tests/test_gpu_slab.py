@@ -116,6 +116,25 @@ def test_rccl_transports(mode, world, tmp_path):
     assert np.all(kn["counts"] > 0) and not np.any(k1["counts"])
 
 
+@pytest.mark.parametrize("mode,min_rows", [("rccl", 16), ("rccl", 512), ("gloo", 16)])
+def test_world8_rehearsal_on_one_gpu(mode, min_rows, tmp_path):
+    """Eight ranks (the world size of BASELINE's config) sharing this box's one GPU: a 64 x 256 channel as eight
+    32-row slabs against the single-rank run.  A rehearsal of the code path (collectives of a world of 8, replicated
+    coarse levels gathered from 8 slabs, V-cycle tail on every rank), not a measurement."""
+    case = "channel_lam_64x256"
+    one = _run(case, 1, tmp_path / "w1")
+    many = _run(case, 8, tmp_path / "w8", min_rows, mode)
+    assert int(one["step"]) == int(many["step"])
+    unorm = max(1.0, np.linalg.norm(one["field_u"].ravel()))
+    for key in [k for k in one.files if k.startswith("field_") and k != "field_p_corr"]:
+        a, b = mask_corners(one[key]), mask_corners(many[key])
+        err, den = np.linalg.norm((a - b).ravel()), np.linalg.norm(a.ravel())
+        assert err <= 1e-10 * den + 1e-12 * unorm, (key, err, den)
+    la, lb = one["log"], many["log"]
+    assert la.shape == lb.shape and np.array_equal(la[:, 2], lb[:, 2])
+    assert np.all(np.abs(la[:, 3] - lb[:, 3]) <= 1e-6 * np.abs(la[:, 3]) + 1e-13)
+
+
 @pytest.mark.parametrize("world", [1, 3])
 def test_slab_mesh_from_rect(world, tmp_path):
     """cfd_mesh_from_rect on slabs (halo node below, cut face row from the rank above) reproduces
