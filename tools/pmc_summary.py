@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a tools/profile_round.sh run into profiles/<tag>_*: kernel stats, FETCH_SIZE / WRITE_SIZE per
-kernel and HBM bytes per cell and launch.  FETCH_SIZE is calibrated on the pure streaming kernels of the
-same run whose read bytes are known (MI355X_MICROARCH.md, HBM: widths other than 16 B per lane are
-uncalibrated - calibrate on a known byte count in the same access pattern); WRITE_SIZE is exact here.
+kernel and HBM bytes per cell and launch.  FETCH_SIZE counts one unit per 2 KiB (MI355X_MICROARCH.md, HBM; confirmed on this
+code's access patterns by tools/stream_probe2.hip under --pmc, profiles/r2_fetch_size_calibration.txt); WRITE_SIZE is exact.
 
     python tools/pmc_summary.py r1g [cells]
 """
@@ -16,7 +15,8 @@ from collections import defaultdict
 tag = sys.argv[1]
 cells = float(sys.argv[2]) if len(sys.argv) > 2 else 8192.0 * 8192.0
 # algorithmic bytes per cell and launch
-ALGO = {"k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 64, "k_mg_up<true>": 42, "k_mg_down<true>": 34, "k_mg_up_k<true, 3>": 42, "k_mg_down_k<true, 3>": 34, "k_cg_r": 24, "k_cg_init": 24,
+ALGO = {"k_chebk<2, 4, 2>": 98.7, "k_chebk<1, 4, 2>": 64, "k_chebk<2, 4, 1>": 98.7, "k_chebk<1, 4, 1>": 64,   # <2,4>: 96 first launch of a solve, 104 later
+        "k_chebk<2, 4>": 104, "k_chebk<1, 4>": 64, "k_cg_pq": 58, "k_mg_up<true>": 42, "k_mg_down<true>": 34, "k_mg_up_k<true, 3>": 42, "k_mg_down_k<true, 3>": 34, "k_cg_r": 24, "k_cg_init": 24,
         "k_cg_xlast": 24, "k_flux_march<0, false>": 104, "k_flux_march<1, false>": 112, "k_flux_march<2, false>": 120,
         "k_continuity": 104, "k_pressure_rhs": 112, "k_momentum_rhs": 120, "k_correct": 136, "k_diffusion_ap": 88,
         "k_dt": 88, "k_rowsum_bound": 24, "k_pressure_coeffs": 64, "k_flux_march<3, false>": 88,
@@ -63,24 +63,26 @@ for name, (t, c) in (("FETCH_SIZE", (ft, fc)), ("WRITE_SIZE", (wt, wc))):
         w.writerow(["kernel", "launches", "total_KB", "avg_KB_per_launch"])
         for k in sorted(t, key=lambda k: -t[k]):
             w.writerow([k, c[k], t[k], t[k] / c[k]])
-# calibration factor of FETCH_SIZE
-ratios = [KNOWN_READS[k] / (ft[k] / fc[k] * 1024.0 / cells) for k in KNOWN_READS if k in ft and ft[k] > 0]
-cal = sum(ratios) / len(ratios) if ratios else 2.0
-with open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv", "w", newline="") as f:
-    f.write(f"# bench.py --steps 1 --warmup 1 --no-cpu at 8192^2, one rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE), KB per launch.\n")
-    f.write(f"# WRITE_SIZE is exact for these stores. FETCH_SIZE calibrated x{cal:.3f} on the pure streaming kernels of the same run whose\n")
-    f.write(f"# read bytes are known ({', '.join(f'{k} {v:g} B/cell' for k, v in KNOWN_READS.items())}); individual factors {', '.join(f'{r:.3f}' for r in ratios)}.\n")
+# FETCH_SIZE unit: 1 KiB that stands for 2 KiB moved (MI355X_MICROARCH.md, HBM: "FETCH_SIZE reports exactly 1/2 of the
+# bytes"; confirmed for THIS code's access patterns by profiles/r2_fetch_size_calibration.txt: 2048.0 B per unit for
+# 8 B-per-lane marching loads, 16 B-per-lane loads and LDS-DMA loads alike, tools/stream_probe2.hip under --pmc).
+# The in-run kernels with known reads are listed for comparison only: they sit above 1.0 because the fabric-side counter
+# sees every 128-B line a 64-lane row touches (five for a row that starts 16 B into a line) and counts Infinity-Cache hits.
+FACTOR = 2.0
+known = {k: (ft[k] / fc[k] * 1024.0 * FACTOR / cells) / KNOWN_READS[k] for k in KNOWN_READS if k in ft and ft[k] > 0}
+with open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv", "w") as f:
+    f.write("# bench.py --steps 1 --warmup 1 --no-cpu at 8192^2, one rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE).\n")
+    f.write("# bytes per cell and launch; fetch = FETCH_SIZE [KiB] x 2 (guide + profiles/r2_fetch_size_calibration.txt), write = WRITE_SIZE [KiB] x 1.\n")
+    f.write("# fabric-side counters: Infinity-Cache hits are counted, so `total` is an upper bound of the HBM bytes.\n")
+    f.write("# kernels with known reads, fetched / algorithmic read bytes: " + ", ".join(f"{k} {v:.3f}" for k, v in known.items()) + "\n")
     f.write(f"# avg_us / share from profiles/{tag}_bench8192_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 3).\n")
-    w = csv.writer(f)
-    w.writerow(["kernel", "launches", "fetch_raw_B_per_cell", "fetch_calibrated_B_per_cell", "write_B_per_cell", "total_B_per_cell",
-                "algorithmic_B_per_cell", "ratio", "avg_us", "share_pct", "algorithmic_TBps"])
+    f.write("kernel;total_B_per_cell;fetch_B_per_cell;write_B_per_cell;algorithmic_B_per_cell;ratio;avg_us;share_pct;launches;algorithmic_TBps\n")
     for k in sorted(ALGO, key=lambda k: -(stats.get(k, (0, 0))[1])):
         if k not in ft or k not in stats:
             continue
-        fr = ft[k] / fc[k] * 1024.0 / cells
+        fr = ft[k] / fc[k] * 1024.0 * FACTOR / cells
         wr = wt.get(k, 0.0) / max(wc.get(k, 1), 1) * 1024.0 / cells
-        tot = fr * cal + wr
         us, share = stats[k]
-        w.writerow([k, fc[k], f"{fr:.2f}", f"{fr * cal:.2f}", f"{wr:.2f}", f"{tot:.2f}", ALGO[k], f"{tot / ALGO[k]:.3f}", f"{us:.1f}",
-                    f"{share:.2f}", f"{ALGO[k] * cells / us / 1e6:.2f}"])
+        f.write(";".join([k, f"{fr + wr:.2f}", f"{fr:.2f}", f"{wr:.2f}", f"{ALGO[k]}", f"{(fr + wr) / ALGO[k]:.3f}", f"{us:.1f}", f"{share:.2f}",
+                          str(fc[k]), f"{ALGO[k] * cells / us / 1e6:.2f}"]) + "\n")
 print(open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv").read())
