@@ -55,6 +55,7 @@ SIGNATURES = {
     "cfd_last_error": (C.c_char_p, []),
     "cfd_version": (C.c_int, []),
     "cfd_ghost_rows": (C.c_int, []),
+    "cfd_col_offset": (C.c_int, []),
     "cfd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "cfd_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]),
     "cfd_destroy": (C.c_int, [_vp]),

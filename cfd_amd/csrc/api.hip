@@ -199,6 +199,7 @@ extern "C" {
 const char *cfd_last_error(void) { return cfd::g_err; }
 int cfd_version(void) { return 100; }
 int cfd_ghost_rows(void) { return cfd::NG; }
+int cfd_col_offset(void) { return cfd::CO; }
 
 size_t cfd_workspace_bytes(int ni, int nj) {
     if (ni < 1 || nj < 2) return 0;         // same bounds as cfd_create

@@ -1,7 +1,7 @@
 // Internal declarations shared by the HIP translation units of libcfd_hip.so.
 // gfx950 only.  Device layout: planes [row][col], col contiguous, NG = CFD_GHOST_ROWS ghost rows below and
-// above the interior rows and two spare columns on the left: interior cell (i, j) lives at
-// (j + NG) * pitch + i + 2 (Geo::cell), so that cell i = 0 is 16-byte aligned; element (ig, jg) of the
+// above the interior rows and CO = CFD_COL_OFFSET spare columns on the left: interior cell (i, j) lives at
+// (j + NG) * pitch + i + CO (Geo::cell), so that cell i = 0 starts a 128-byte line; element (ig, jg) of the
 // reference's ghosted (Ni+2) x (Nj+2) array is Geo::at(ig, jg) = cell(ig - 1, jg - 1).  Face planes share
 // the geometry: i-face f (west face of cell f) sits at the index of cell f, j-face g (south face) at cell g.
 #pragma once
@@ -28,6 +28,13 @@ constexpr int MAX_LEVELS = 24;
 // others are halo rows of the fused kernels (three smoothing sweeps, four Chebyshev iterations per pass) and of
 // the j-slab exchange.  Plane row r holds j = r - NG.
 constexpr int NG = CFD_GHOST_ROWS;
+// Interior cell i = 0 sits CO doubles into its plane row: one full 128-byte line, so that a 64-lane row of a tile
+// kernel (columns 64 t .. 64 t + 63) covers exactly four lines instead of straddling five (the fabric-side
+// FETCH_SIZE of the pointwise kernels was 1.19 - 1.25 times their algorithmic reads with the former offset of 2).
+#ifndef CFD_CO
+#define CFD_CO CFD_COL_OFFSET
+#endif
+constexpr int CO = CFD_CO;
 
 struct Geo {
     int ni, nj, pitch;
@@ -39,12 +46,12 @@ struct Geo {
     __host__ __device__ inline bool bhi(int j) const { return j == nj - 1 && !cuthi; }     // physical high-j boundary row
     // NG ghost rows below and above the interior: the innermost one is the reference's ghost layer, the
     // others are halo rows of the fused kernels / of the j-slab exchange.  ghosted index jg = j + 1.
-    __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)(jg + NG - 1) * pitch + ig + 1; }
-    __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + NG) * pitch + i + 2; }
+    __host__ __device__ inline size_t at(int ig, int jg) const { return (size_t)(jg + NG - 1) * pitch + ig + CO - 1; }
+    __host__ __device__ inline size_t cell(int i, int j) const { return (size_t)(j + NG) * pitch + i + CO; }
     __host__ inline size_t plane_elems() const { return (size_t)(nj + 2 * NG) * pitch; }
 };
 
-inline int pitch_for(int ni) { return ((ni + 4) + 31) / 32 * 32; }
+inline int pitch_for(int ni) { return ((ni + CO + 2) + 31) / 32 * 32; }
 
 struct MeshDev {
     const double *vol, *wri, *wnj, *nix, *niy, *njx, *njy, *si, *sj, *di, *dj, *lmin;

@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, DiagFix 
         const int iraw = strip * MW - MH + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // software pipeline: the next pair of rows is loaded while the current pair is processed
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, DiagFix 
             if (!df.on || mr == g.nj + 2 * NG - 1) R.row = -1000000;
         };
         auto mk = [&](const Raw &R) -> RowC {
-            const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
+            const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - CO, R.row, df, op) : R.d;
             return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
         };
         bool v2, v1;
@@ -963,8 +963,8 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df
         const int iraw = strip * MW - MH + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
-        const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
+        const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + CO;
         const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // software pipeline: the next pair of rows is loaded while the current pair is processed
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df
             R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
         };
         auto mk = [&](const Raw &R) -> RowC {
-            const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
+            const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - CO, R.row, df, op) : R.d;
             return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
         };
         bool v2, v1;
@@ -1094,7 +1094,7 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
     R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
 }
 __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const OpDev &op, size_t colo) {
-    const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, R.row, df, op) : R.d;
+    const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - CO, R.row, df, op) : R.d;
     return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
 }
 
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFi
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // RC[s], V[s]: operator row / validity of row j - s;  X[s][0..2]: sweep s on rows (r - 2, r - 1, r), r = j - (s - 1)
@@ -1184,8 +1184,8 @@ __global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix 
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
-        const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
+        const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + CO;
         const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // RC[s], V[s]: row j - s;  X[s][0..2]: iterate after s sweeps on rows (r - 2, r - 1, r), r = j - s
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(64 * LJ_WAVES) void k_line_j(OpDev op, LineGeo lg, 
         const int iraw = strip * lg.wstrip - 1 + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const bool out = lane >= 1 && lane <= lg.wstrip && iraw < g.ni;
         const int j0 = seg * lg.Ls, j1 = min(j0 + lg.Ls, g.nj);
         // old iterate on the rows just outside the block (explicit couplings); zero outside the domain
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(256) void k_line_i(OpDev op, LineGeo lg, const doub
         const int iraw = strip * lg.wstrip - 1 + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const bool act = lane >= 1 && lane <= lg.wstrip && iraw < g.ni;      // unknowns of this block
         const int j0 = seg * lg.Ls, j1 = min(j0 + lg.Ls, g.nj);
         auto xrow = [&](int j) -> double {
@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(256) void k_cheb2(OpDev op, MarchGeo mg, double c1a
         const int iraw = strip * MW - MH + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const bool out = lane >= MH && lane < 64 - MH && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // row j: operator row + x_k ; returns the cell index (clamped to a valid cell when outside)
@@ -1645,7 +1645,7 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // north coupling of the last row of a periodic-j mesh (and of its wrapped copy, row -1): the seam's own entry
@@ -2682,7 +2682,7 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df
         const int iraw = strip * 62 - 1 + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
-        const size_t colo = (size_t)(cvalid ? col : 0) + 2;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const bool out = lane >= 1 && lane < 63 && iraw < g.ni;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         double pa = 0.0, pb = 0.0, pc, po_b = 0.0, po_c;
@@ -2705,7 +2705,7 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df
             R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
             // rows j0-1 .. j1 only: the outermost halo row is never touched here
-            R.d = df.on ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - 2, (mr >= 0 ? mr : NG) - NG, df, op) : op.D[cc];
+            R.d = df.on ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - CO, (mr >= 0 ? mr : NG) - NG, df, op) : op.D[cc];
         };
         RowIn nxt;
         fetch(j0 - 1, nxt);

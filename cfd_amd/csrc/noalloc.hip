@@ -112,7 +112,7 @@ extern "C" int cfd_bulk_velocity_noalloc(const double *field_dev, const double *
         set_error("cfd_bulk_velocity_noalloc: %d x %d cells outside the supported 1 .. %d per side", ni, nj, NA_MAX_SIDE);
         return CFD_E_ARG;
     }
-    if (pitch < ni + 4 || pitch % 2) { set_error("cfd_bulk_velocity_noalloc: pitch %d too small for %d columns (need >= ni + 4, even)", pitch, ni); return CFD_E_ARG; }
+    if (pitch < ni + CO + 2 || pitch % 2) { set_error("cfd_bulk_velocity_noalloc: pitch %d too small for %d columns (need >= ni + %d, even)", pitch, ni, CO + 2); return CFD_E_ARG; }
     double *ptr = nullptr;
     CFD_TRY(scratch_ptr(&ptr));
     Geo g{};

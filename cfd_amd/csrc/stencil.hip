@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
         const int strip = item % fm.nstrips, seg = item / fm.nstrips;
         const int iraw = strip * FXW - 1 + lane;          // -1 .. ni : ghost columns included
         const int ic = iraw < g.ni ? iraw : g.ni;
-        const size_t colo = (size_t)(ic + 2);
+        const size_t colo = (size_t)(ic + CO);
         const bool out = lane >= 1 && lane <= FXW && iraw < g.ni;
         const bool ilo = iraw == 0, ihi = iraw == g.ni;
         const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);

@@ -32,7 +32,7 @@ class Device:
 
     @property
     def pitch(self):
-        """Row pitch of the device planes in doubles (cell (i, j) sits at (j + GHOST_ROWS) * pitch + i + 2)."""
+        """Row pitch of the device planes in doubles (cell (i, j) sits at (j + CFD_GHOST_ROWS) * pitch + i + CFD_COL_OFFSET)."""
         return int(self.lib.cfd_pitch(self._h))
 
     def comm_counts(self):

@@ -55,6 +55,10 @@ enum { CFD_TURB_KOMEGA = 0, CFD_TURB_SST = 1 };
  * the halo callback of a j-slab host addresses rows with it (cfd_set_comm); depth <= CFD_GHOST_ROWS.        */
 #define CFD_GHOST_ROWS 4
 int cfd_ghost_rows(void);
+/* Columns to the left of interior column i = 0 in every plane row (one 128-byte line; the last of them is the
+ * reference's ghost column): interior cell (i, j) of a plane sits at (j + CFD_GHOST_ROWS) * pitch + i + CFD_COL_OFFSET. */
+#define CFD_COL_OFFSET 16
+int cfd_col_offset(void);
 
 /* array kinds (host shapes) */
 enum { CFD_KIND_CELL_GHOSTED = 0, CFD_KIND_CELL = 1, CFD_KIND_FACE_I = 2, CFD_KIND_FACE_J = 3 };

@@ -11,12 +11,12 @@ from oracle import cfd_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def _planes(torch, ni, nj, pitch, ng, vol, u):
-    """Device planes in the library's layout: cell (i, j) at (j + ng) * pitch + i + 2."""
+def _planes(torch, ni, nj, pitch, ng, vol, u, co):
+    """Device planes in the library's layout: cell (i, j) at (j + ng) * pitch + i + co (CFD_GHOST_ROWS, CFD_COL_OFFSET)."""
     out = []
     for a in (u, vol):
         host = np.zeros((nj + 2 * ng, pitch))
-        host[ng:ng + nj, 2:2 + ni] = a.T
+        host[ng:ng + nj, co:co + ni] = a.T
         out.append(torch.from_numpy(host).cuda())
     return out
 
@@ -41,7 +41,7 @@ def test_no_alloc_entry_point_matches_bulk_velocity():
         want = dev.bulk_velocity(L.F_U)
         pitch = dev.pitch
         dev.close()
-        f_pl, w_pl = _planes(torch, ni, nj, pitch, ng, mesh["cell_volume"], u[1:-1, 1:-1])
+        f_pl, w_pl = _planes(torch, ni, nj, pitch, ng, mesh["cell_volume"], u[1:-1, 1:-1], lib.cfd_col_offset())
         out = torch.full((3,), float("nan"), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
         stream = torch.cuda.current_stream().cuda_stream
