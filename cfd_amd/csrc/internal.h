@@ -124,6 +124,14 @@ __device__ __forceinline__ double lane_right(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by their index (block b runs on XCD b % 8), and each XCD has its own
+// L2.  Neighbouring column strips share halo lanes, neighbouring row segments share halo rows: with this map the
+// blocks of one XCD own a contiguous run of work items, so the lines two neighbours share are fetched into one L2
+// instead of two.  nb (the grid) must be a multiple of 8.  (Measured slower than the plain map, see Ctx::xcd_map.)
+__device__ __forceinline__ int xcd_block(int b, int nb, int on) {
+    return on ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+}
+
 // Streaming store: planes larger than the 256 MiB Infinity Cache are written once and read back only after
 // everything else has passed through the cache, so their stores carry the nontemporal hint (tools/stream_probe2.hip:
 // +5-8 % on the marching access pattern with plain loads; nontemporal LOADS lose, they bypass the L1 reuse of
@@ -311,6 +319,11 @@ struct Ctx {
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
     double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this
     double mg_line_omega = 0.8;
+    // Contiguous-per-XCD block -> work item map of the marching kernels (A-B switch "xcd_map").  Measured at 8192^2: the
+    // map LOSES 18 % (k_chebk) to 40 % (k_mg_up_k) against the plain one, where the eight XCDs stream neighbouring strips
+    // of the same rows at the same time (DRAM pages stay open across the channels); the halo lines two XCDs then both
+    // fetch cost less than that.  Off.
+    int xcd_map = 0;
     int mg_tail = 1;             // 1: levels that fit one workgroup's LDS are cycled by one launch
     int tail_lt = -1;            // first level of the tail (-1: none), set when the hierarchy is built
     TailArgs tail{};

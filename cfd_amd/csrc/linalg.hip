@@ -847,6 +847,7 @@ __device__ __forceinline__ double resid(double xc, double xs, double xn, const R
 
 struct MarchGeo {
     int nstrips, nsegs, Ls;
+    int xcd = 0;         // 1: xcd_block() map (the grid is then a multiple of 8)
 };
 static inline MarchGeo march_geo(const Geo &g) {
     MarchGeo m;
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFi
     const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     constexpr int W = 64 - 2 * K;
-    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
         const int strip = item % mg.nstrips, seg = item / mg.nstrips;
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
@@ -1179,7 +1180,7 @@ __global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix 
     const size_t P = g.pitch;
     constexpr int W = 64 - 2 * K;
     double dot = 0.0;
-    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
         const int strip = item % mg.nstrips, seg = item / mg.nstrips;
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
@@ -1437,7 +1438,8 @@ static inline bool level_fusable(const Ctx *c, int lvl, const Geo &F, const Geo 
 static inline MarchGeo march_geo_k(const Geo &g, int K);
 static inline int march_blocks(const MarchGeo &m) {
     const long items = (long)m.nstrips * m.nsegs;
-    const long nb = (items + 3) / 4;
+    long nb = (items + 3) / 4;
+    if (m.xcd) nb = (nb + 7) / 8 * 8;
     return (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
 }
 // K halo lanes / rows per side: narrower strips, longer segments to amortise the 2K extra rows
@@ -1640,7 +1642,7 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
     double acc[3 * NB];
 #pragma unroll
     for (int q = 0; q < 3 * NB; ++q) acc[q] = 0.0;
-    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
         const int strip = item % mg.nstrips, seg = item / mg.nstrips;
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
@@ -1816,6 +1818,7 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         while (Ls > 8 && (long)mgeo.nstrips * ((g.nj + Ls - 1) / Ls) < 8192) Ls /= 2;
         mgeo.Ls = Ls;
         mgeo.nsegs = (g.nj + Ls - 1) / Ls;
+        mgeo.xcd = c->xcd_map;
     }
     const dim3 grid(march_blocks(mgeo));
     // iterate buffers: launch m writes x_{Km-1}, x_{Km} into set m & 1 and reads set (m - 1) & 1
@@ -2439,7 +2442,8 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         const Geo cg = coarse_view(c, l + 1);
         double *cb = to_agg ? C.s0 : C.b;
         if (level_fusable(c, l, L.g, cg)) {
-            const MarchGeo mgeo = march_geo_k(L.g, KS);
+            MarchGeo mgeo = march_geo_k(L.g, KS);
+            mgeo.xcd = KS == 3 ? c->xcd_map : 0;
             const dim3 grid(march_blocks(mgeo));
             if (++n_fused_levels > c->kc[KC_MG_FUSED_LEVELS_MAX]) c->kc[KC_MG_FUSED_LEVELS_MAX] = n_fused_levels;
             if (l == 0 && rf) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rf->q)));      // r_old's rows are there already
@@ -2550,7 +2554,8 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
         else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, level_fusable(c, l, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
         if (level_fusable(c, l, L.g, cg)) {
-            const MarchGeo mgeo = march_geo_k(L.g, KS);
+            MarchGeo mgeo = march_geo_k(L.g, KS);
+            mgeo.xcd = KS == 3 ? c->xcd_map : 0;
             const dim3 grid(march_blocks(mgeo));
             if (!x_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, cur[l]));
             if (l == 0) {
@@ -2677,7 +2682,7 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df
     const double beta = first ? 0.0 : safe_div(s->rz[gen], s->rz[gen ^ 1]);
     const double alpha_prev = first ? 0.0 : safe_div(s->rz[gen ^ 1], s->pq);
     double dot = 0.0;
-    for (int item = blockIdx.x * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
+    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
         const int strip = item % mg.nstrips, seg = item / mg.nstrips;
         const int iraw = strip * 62 - 1 + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
@@ -2802,6 +2807,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     double *pbuf[2] = {c->kry[2], c->kry[6]};
     MarchGeo mgeo = march_geo(g);
     mgeo.nstrips = (g.ni + 61) / 62;
+    mgeo.xcd = c->xcd_map;
     const dim3 mgrid(march_blocks(mgeo));
     CFD_HIP(hipMemsetAsync(S, 0, sizeof(CgScal), st));
     if (fused) {
