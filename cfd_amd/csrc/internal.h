@@ -132,6 +132,43 @@ __device__ __forceinline__ int xcd_block(int b, int nb, int on) {
     return on ? (b & 7) * (nb >> 3) + (b >> 3) : b;
 }
 
+// Work items of a marching kernel.  WPB = 4: every wave takes (strip, segment) items on its own.  WPB = 8 / 16, the
+// lockstep form: a workgroup takes WPB neighbouring strips of ONE segment and its waves meet at a barrier after every
+// row step, so that the workgroup reads WPB x 512 contiguous bytes of each plane row at a time (the strips' 64-lane
+// windows are not aligned to the 128-byte lines; waves drifting apart made each of them pay for its two partial lines:
+// tools/stream_probe3.hip, 4.1 TB/s for misaligned independent waves, 4.8 - 4.9 in lockstep).  Every wave of a lockstep
+// workgroup has the same segment, hence the same trip counts; a wave beyond the last strip repeats the last strip
+// without output, so that it reaches the same barriers.
+template <int WPB, bool LOCK = (WPB > 4)>
+struct MarchItems {
+    int first, stride, count, ngroups;
+    __device__ __forceinline__ MarchItems(int nstrips, int nsegs, int xcd, int wave) {
+        ngroups = (nstrips + WPB - 1) / WPB;
+        if (LOCK) { first = blockIdx.x; stride = gridDim.x; count = ngroups * nsegs; }
+        else { first = xcd_block(blockIdx.x, gridDim.x, xcd) * 4 + wave; stride = gridDim.x * 4; count = nstrips * nsegs; }
+    }
+    __device__ __forceinline__ void decode(int item, int nstrips, int wave, int &strip, int &seg, bool &active) const {
+        if (LOCK) {
+            const int raw = (item % ngroups) * WPB + wave;
+            active = raw < nstrips;
+            strip = active ? raw : nstrips - 1;
+            seg = item / ngroups;
+        } else {
+            active = true;
+            strip = item % nstrips;
+            seg = item / nstrips;
+        }
+    }
+};
+// sum of the per-wave values of a workgroup of WPB waves (WPB a multiple of 4), fixed order
+template <int WPB>
+__device__ __forceinline__ double sum_waves(const double *sm) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < WPB; q += 4) tot += (sm[q] + sm[q + 1]) + (sm[q + 2] + sm[q + 3]);
+    return tot;
+}
+
 // Streaming store: planes larger than the 256 MiB Infinity Cache are written once and read back only after
 // everything else has passed through the cache, so their stores carry the nontemporal hint (tools/stream_probe2.hip:
 // +5-8 % on the marching access pattern with plain loads; nontemporal LOADS lose, they bypass the L1 reuse of
@@ -324,6 +361,12 @@ struct Ctx {
     // of the same rows at the same time (DRAM pages stay open across the channels); the halo lines two XCDs then both
     // fetch cost less than that.  Off.
     int xcd_map = 0;
+    // marching kernels that run as lockstep workgroups of 8 neighbouring strips (MarchItems<8>); bits: 1 k_cg_pq,
+    // 2 k_chebk with one right-hand side, 4 with two, 8 k_mg_up_k (finest level), 16 k_mg_down_k with the PCG residual
+    // update, 32 k_mg_down_k (finest level), 64 the coarse levels of both, 128 k_flux_march (momentum and pressure
+    // right-hand sides), 256 k_chebk with two right-hand sides as lockstep workgroups of FOUR strips (its 222 registers
+    // allow two waves per SIMD either way).  Default: what measured faster at 8192^2.
+    int wide_mask = 1 | 2 | 8 | 16 | 128 | 256;
     int mg_tail = 1;             // 1: levels that fit one workgroup's LDS are cycled by one launch
     int tail_lt = -1;            // first level of the tail (-1: none), set when the hierarchy is built
     TailArgs tail{};

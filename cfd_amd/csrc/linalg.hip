@@ -1099,22 +1099,24 @@ __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const 
     return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
 }
 
-template <bool FINE, int K, bool RF = false>
-__global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
-                                                   Geo gc, double *bc, ResidFuse rf = ResidFuse{}, int nts = 0) {
+template <bool FINE, int K, bool RF = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
+                                                        Geo gc, double *bc, ResidFuse rf = ResidFuse{}, int nts = 0) {
     const Geo g = op.g;
     const double alpha = RF ? safe_div(rf.rz[0], rf.pq[0]) : 0.0;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
-    const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     constexpr int W = 64 - 2 * K;
-    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
-        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+    const MarchItems<WPB> items(mg.nstrips, mg.nsegs, mg.xcd, wave);
+    for (int item = items.first; item < items.count; item += items.stride) {
+        int strip, seg;
+        bool active;
+        items.decode(item, mg.nstrips, wave, strip, seg, active);
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
         const size_t colo = (size_t)(cvalid ? col : 0) + CO;
-        const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
+        const bool out = lane >= K && lane < 64 - K && iraw < g.ni && active;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // RC[s], V[s]: operator row / validity of row j - s;  X[s][0..2]: sweep s on rows (r - 2, r - 1, r), r = j - (s - 1)
         RowC RC[K + 1];
@@ -1167,27 +1169,30 @@ __global__ __launch_bounds__(256) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFi
             for (int s2 = K; s2 >= 1; --s2) { RC[s2] = RC[s2 - 1]; V[s2] = V[s2 - 1]; }
 #pragma unroll
             for (int s2 = 1; s2 <= K; ++s2) { X[s2][0] = X[s2][1]; X[s2][1] = X[s2][2]; }
+            if (WPB > 4) __syncthreads();       // lockstep: same segment, same trip count for every wave of the workgroup
         }
     }
 }
 
-template <bool FINE, int K>
-__global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
-                                                 const double *e, double gamma, SweepOm<K> om, double *xn, double *partials, int nts = 0) {
+template <bool FINE, int K, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
+                                                      const double *e, double gamma, SweepOm<K> om, double *xn, double *partials, int nts = 0) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
-    const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     constexpr int W = 64 - 2 * K;
     double dot = 0.0;
-    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
-        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+    const MarchItems<WPB> items(mg.nstrips, mg.nsegs, mg.xcd, wave);
+    for (int item = items.first; item < items.count; item += items.stride) {
+        int strip, seg;
+        bool active;
+        items.decode(item, mg.nstrips, wave, strip, seg, active);
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
         const size_t colo = (size_t)(cvalid ? col : 0) + CO;
         const size_t coloc = (size_t)((cvalid ? col : 0) >> 1) + CO;
-        const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
+        const bool out = lane >= K && lane < 64 - K && iraw < g.ni && active;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // RC[s], V[s]: row j - s;  X[s][0..2]: iterate after s sweeps on rows (r - 2, r - 1, r), r = j - s
         RowC RC[K + 1];
@@ -1224,14 +1229,15 @@ __global__ __launch_bounds__(256) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix 
             for (int s2 = K; s2 >= 1; --s2) { RC[s2] = RC[s2 - 1]; V[s2] = V[s2 - 1]; }
 #pragma unroll
             for (int s2 = 0; s2 <= K; ++s2) { X[s2][0] = X[s2][1]; X[s2][1] = X[s2][2]; }
+            if (WPB > 4) __syncthreads();       // lockstep
         }
     }
     if (FINE) {
-        __shared__ double sm[4];
+        __shared__ double sm[WPB];
         const double w = wsum(dot);
         if (lane == 0) sm[wave] = w;
         __syncthreads();
-        if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        if (threadIdx.x == 0) partials[blockIdx.x] = sum_waves<WPB>(sm);
     }
 }
 
@@ -1442,6 +1448,17 @@ static inline int march_blocks(const MarchGeo &m) {
     if (m.xcd) nb = (nb + 7) / 8 * 8;
     return (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
 }
+// lockstep workgroups (MarchItems<8>): on meshes with enough strips to fill them
+// which: WIDE_* bit of the kernel asking (Ctx::wide_mask holds the kernels that measured faster in lockstep)
+enum { WIDE_CG_PQ = 1, WIDE_CHEB1 = 2, WIDE_CHEB2 = 4, WIDE_MG_UP = 8, WIDE_MG_DOWN_RF = 16, WIDE_MG_DOWN = 32, WIDE_MG_COARSE = 64 };
+static inline int march_wide(const Ctx *c, const MarchGeo &m, int which) {
+    return ((c->wide_mask & which) && m.nstrips >= 16) ? 8 : 4;
+}
+static inline int march_grid(const MarchGeo &m, int wide, bool lock4 = false) {
+    if (wide <= 4 && !lock4) return march_blocks(m);
+    const long items = (long)((m.nstrips + wide - 1) / wide) * m.nsegs;
+    return (int)(items < MAX_PARTIALS ? items : MAX_PARTIALS);
+}
 // K halo lanes / rows per side: narrower strips, longer segments to amortise the 2K extra rows
 static inline MarchGeo march_geo_k(const Geo &g, int K) {
     if (K <= 2) return march_geo(g);
@@ -1631,24 +1648,26 @@ struct ChebStages {
 struct RowB {
     double d, inv, cw, ce, cs;
 };
-template <int NB, int K, int PF>
-__global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages<K> cf, int first, int nts, CVecs<NB> b,
-                                               CVecs<NB> xk, CVecs<NB> xm, Vecs<NB> xlo, Vecs<NB> xhi, double *partials) {
+template <int NB, int K, int PF, int WPB = 4, bool LOCK = (WPB > 4)>
+__global__ __launch_bounds__(64 * WPB) void k_chebk(OpDev op, MarchGeo mg, ChebStages<K> cf, int first, int nts, CVecs<NB> b,
+                                                    CVecs<NB> xk, CVecs<NB> xm, Vecs<NB> xlo, Vecs<NB> xhi, double *partials) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
-    const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     constexpr int W = 64 - 2 * K;
     double acc[3 * NB];
 #pragma unroll
     for (int q = 0; q < 3 * NB; ++q) acc[q] = 0.0;
-    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
-        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+    const MarchItems<WPB, LOCK> items(mg.nstrips, mg.nsegs, mg.xcd, wave);
+    for (int item = items.first; item < items.count; item += items.stride) {
+        int strip, seg;
+        bool active;
+        items.decode(item, mg.nstrips, wave, strip, seg, active);
         const int iraw = strip * W - K + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
         const size_t colo = (size_t)(cvalid ? col : 0) + CO;
-        const bool out = lane >= K && lane < 64 - K && iraw < g.ni;
+        const bool out = lane >= K && lane < 64 - K && iraw < g.ni && active;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         // north coupling of the last row of a periodic-j mesh (and of its wrapped copy, row -1): the seam's own entry
         const double cn_top = op.per_j ? op.cj[(size_t)(g.nj + NG) * P + colo] : 0.0;
@@ -1757,6 +1776,7 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
                     fetch(j + 3, r1);
                     trip(j + 1, cur);
                 }
+                if (LOCK) __syncthreads();       // lockstep: ja, jb depend on the segment only
             }
         } else {
             RowIn nxt;
@@ -1765,19 +1785,18 @@ __global__ __launch_bounds__(256) void k_chebk(OpDev op, MarchGeo mg, ChebStages
                 const RowIn cur = nxt;
                 fetch(j + 1, nxt);
                 trip(j, cur);
+                if (LOCK) __syncthreads();
             }
         }
     }
-    __shared__ double sm[3 * NB][4];
+    __shared__ double sm[3 * NB][WPB];
 #pragma unroll
     for (int q = 0; q < 3 * NB; ++q) {
         const double w = wsum(acc[q]);
         if (lane == 0) sm[q][wave] = w;
     }
     __syncthreads();
-    if (threadIdx.x < 3 * NB)
-        partials[(size_t)threadIdx.x * MAX_PARTIALS + blockIdx.x] =
-            (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+    if (threadIdx.x < 3 * NB) partials[(size_t)threadIdx.x * MAX_PARTIALS + blockIdx.x] = sum_waves<WPB>(sm[threadIdx.x]);
 }
 
 // Chebyshev coefficient stream of Saad's Algorithm 12.1 on [1 - rho, 1 + rho]
@@ -1820,7 +1839,9 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         mgeo.nsegs = (g.nj + Ls - 1) / Ls;
         mgeo.xcd = c->xcd_map;
     }
-    const dim3 grid(march_blocks(mgeo));
+    // lockstep workgroups: per launch (one or two right-hand sides), see the loop
+    const bool wide_ok = K == 4 && c->cheb_prefetch == 2;
+    const int wide2 = wide_ok ? march_wide(c, mgeo, WIDE_CHEB2) : 4, wide1 = wide_ok ? march_wide(c, mgeo, WIDE_CHEB1) : 4;
     // iterate buffers: launch m writes x_{Km-1}, x_{Km} into set m & 1 and reads set (m - 1) & 1
     double *set[2][2][NB];
     CVecs<NB> bc;
@@ -1880,6 +1901,9 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         ChebStages<K> cf;
         for (int s2 = 0; s2 < K; ++s2) cc.next(cf.c1[s2], cf.c2[s2]);
         const int probe_id = (na == 2) ? 8 : 9;      // 8: both right-hand sides in the launch, 9: one
+        const int wide = na == 2 ? wide2 : wide1;
+        const bool lock4 = wide == 4 && na == 2 && NB == 2 && wide_ok && (c->wide_mask & 256) && mgeo.nstrips >= 16;
+        const dim3 grid(march_grid(mgeo, wide, lock4));
         c->probe_begin(probe_id);
         if (na == NB) {
             CVecs<NB> xk, xm;
@@ -1891,6 +1915,12 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             if (K == 2)
                 hipLaunchKernelGGL((k_cheb2<NB>), grid, dim3(256), 0, st, op, mgeo, cf.c1[0], cf.c2[0], cf.c1[1], cf.c2[1],
                                    m == 1 ? 1 : 0, bc, xk, xm, o1, o2, c->partials);
+            else if (wide == 8)
+                hipLaunchKernelGGL((k_chebk<NB, K, 2, 8>), grid, dim3(512), 0, st, op, mgeo, cf, m == 1 ? 1 : 0, c->nts(), bc, xk, xm, o1, o2,
+                                   c->partials);
+            else if (lock4)
+                hipLaunchKernelGGL((k_chebk<NB, K, 2, 4, true>), grid, dim3(256), 0, st, op, mgeo, cf, m == 1 ? 1 : 0, c->nts(), bc, xk, xm, o1, o2,
+                                   c->partials);
             else if (c->cheb_prefetch == 2)
                 hipLaunchKernelGGL((k_chebk<NB, K, 2>), grid, dim3(256), 0, st, op, mgeo, cf, m == 1 ? 1 : 0, c->nts(), bc, xk, xm, o1, o2,
                                    c->partials);
@@ -1904,6 +1934,8 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             if (K == 2)
                 hipLaunchKernelGGL((k_cheb2<1>), grid, dim3(256), 0, st, op, mgeo, cf.c1[0], cf.c2[0], cf.c1[1], cf.c2[1], 0, b1, xk,
                                    xm, o1, o2, c->partials);
+            else if (wide == 8)
+                hipLaunchKernelGGL((k_chebk<1, K, 2, 8>), grid, dim3(512), 0, st, op, mgeo, cf, 0, c->nts(), b1, xk, xm, o1, o2, c->partials);
             else if (c->cheb_prefetch == 2)
                 hipLaunchKernelGGL((k_chebk<1, K, 2>), grid, dim3(256), 0, st, op, mgeo, cf, 0, c->nts(), b1, xk, xm, o1, o2, c->partials);
             else
@@ -2403,6 +2435,13 @@ static int line_smooth(Ctx *c, const Level &L, const OpDev &op, const double *rh
     return CFD_OK;
 }
 
+// independent-wave (256 threads) or lockstep (512 threads, MarchItems<8>) form of a marching kernel
+#define LAUNCH_WIDE(wide, K4, K8, grid, ...)                                             \
+    do {                                                                                 \
+        if ((wide) == 8) hipLaunchKernelGGL(K8, grid, dim3(512), 0, st, __VA_ARGS__);   \
+        else hipLaunchKernelGGL(K4, grid, dim3(256), 0, st, __VA_ARGS__);               \
+    } while (0)
+
 // One V-cycle: z ~= A^-1 r starting from zero.  The result lands in *zout, which is
 // either z0 or z1 (Jacobi ping-pong).
 static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks,
@@ -2444,7 +2483,8 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (level_fusable(c, l, L.g, cg)) {
             MarchGeo mgeo = march_geo_k(L.g, KS);
             mgeo.xcd = KS == 3 ? c->xcd_map : 0;
-            const dim3 grid(march_blocks(mgeo));
+            const int wide = KS == 3 ? march_wide(c, mgeo, l > 0 ? WIDE_MG_COARSE : (rf ? WIDE_MG_DOWN_RF : WIDE_MG_DOWN)) : 4;
+            const dim3 grid(march_grid(mgeo, wide));
             if (++n_fused_levels > c->kc[KC_MG_FUSED_LEVELS_MAX]) c->kc[KC_MG_FUSED_LEVELS_MAX] = n_fused_levels;
             if (l == 0 && rf) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rf->q)));      // r_old's rows are there already
             else if (!rhs_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
@@ -2452,19 +2492,19 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 // rhs[0] is r_old here; the kernel leaves r = r_old - alpha q in rf->rnew, which the way up reads
                 if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
                 c->probe_begin(10);
-                hipLaunchKernelGGL((k_mg_down_k<true, 3, true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g));
+                LAUNCH_WIDE(wide, (k_mg_down_k<true, 3, true>), (k_mg_down_k<true, 3, true, 8>), grid, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g));
                 c->probe_end(10, 50.0);
                 c->kc[KC_MG_DEFERRED_RESID] += 1;
                 rhs[0] = rf->rnew;
             } else if (l == 0) {
                 c->probe_begin(1);
                 if (KS == 3)
-                    hipLaunchKernelGGL((k_mg_down_k<true, 3>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
+                    LAUNCH_WIDE(wide, (k_mg_down_k<true, 3>), (k_mg_down_k<true, 3, false, 8>), grid, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
                 else
                     hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
                 c->probe_end(1, c->p_diag.on ? 34.0 : 42.0);
             } else if (KS == 3) {
-                hipLaunchKernelGGL((k_mg_down_k<false, 3>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
+                LAUNCH_WIDE(wide, (k_mg_down_k<false, 3>), (k_mg_down_k<false, 3, false, 8>), grid, op, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
             } else {
                 hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om, om2, cur[l], cg, cb);
             }
@@ -2556,21 +2596,22 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (level_fusable(c, l, L.g, cg)) {
             MarchGeo mgeo = march_geo_k(L.g, KS);
             mgeo.xcd = KS == 3 ? c->xcd_map : 0;
-            const dim3 grid(march_blocks(mgeo));
+            const int wide = KS == 3 ? march_wide(c, mgeo, l > 0 ? WIDE_MG_COARSE : WIDE_MG_UP) : 4;
+            const dim3 grid(march_grid(mgeo, wide));
             if (!x_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, cur[l]));
             if (l == 0) {
                 c->probe_begin(7);
                 if (KS == 3)
-                    hipLaunchKernelGGL((k_mg_up_k<true, 3>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
-                                       om3, oth[l], c->partials, c->nts(L.g));
+                    LAUNCH_WIDE(wide, (k_mg_up_k<true, 3>), (k_mg_up_k<true, 3, 8>), grid, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
+                                om3, oth[l], c->partials, c->nts(L.g));
                 else
                     hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                        oth[l], c->partials);
                 c->probe_end(7, c->p_diag.on ? 42.0 : 50.0);
                 *dot_blocks = (int)grid.x;
             } else if (KS == 3) {
-                hipLaunchKernelGGL((k_mg_up_k<false, 3>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
-                                   oth[l], c->partials, c->nts(L.g));
+                LAUNCH_WIDE(wide, (k_mg_up_k<false, 3>), (k_mg_up_k<false, 3, 8>), grid, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
+                            oth[l], c->partials, c->nts(L.g));
             } else {
                 hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);
@@ -2672,23 +2713,36 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 // 72 B/cell (z, p, x, D, c_i, c_j read; p', q, x written) instead of 24 + 40 for k_cg_p + k_cg_q and
 // 16 of the 48 of k_cg_xr, whose remainder is k_cg_r below.  p' goes to a second plane: neighbouring
 // strips recompute p' on their halo from the old p.
-__global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen, int first, int xzero,
-                                               const double *z, const double *pold, double *pnew, double *q, double *x, double *partials,
-                                               int nts) {
+// WPB = 4: every wave takes work items (strip, segment) on its own.  WPB = 8 / 16 (lockstep form): a workgroup takes
+// WPB neighbouring strips of ONE segment and its waves meet at a barrier after every row, so that the workgroup reads
+// WPB x 512 contiguous bytes of each plane row at a time -- the strips' 64-lane windows are not aligned to the
+// 128-byte lines (62 output columns per strip), and waves drifting apart made every one of them pay for its two
+// partial lines (tools/stream_probe3.hip: 4.1 TB/s for misaligned independent waves, 4.8 - 4.9 in lockstep).
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen, int first, int xzero,
+                                                    const double *z, const double *pold, double *pnew, double *q, double *x, double *partials,
+                                                    int nts) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
-    const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     const double beta = first ? 0.0 : safe_div(s->rz[gen], s->rz[gen ^ 1]);
     const double alpha_prev = first ? 0.0 : safe_div(s->rz[gen ^ 1], s->pq);
     double dot = 0.0;
-    for (int item = xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave; item < mg.nstrips * mg.nsegs; item += nw) {
-        const int strip = item % mg.nstrips, seg = item / mg.nstrips;
+    constexpr bool LOCK = WPB > 4;
+    const int ngroups = (mg.nstrips + WPB - 1) / WPB;
+    const int n_items = LOCK ? ngroups * mg.nsegs : mg.nstrips * mg.nsegs;
+    const int first_item = LOCK ? (int)blockIdx.x : xcd_block(blockIdx.x, gridDim.x, mg.xcd) * 4 + wave;
+    const int stride = LOCK ? (int)gridDim.x : (int)gridDim.x * 4;
+    for (int item = first_item; item < n_items; item += stride) {
+        // lockstep: (group of WPB strips, segment) per workgroup; a wave beyond the last strip repeats it without output
+        const int strip_raw = LOCK ? (item % ngroups) * WPB + wave : item % mg.nstrips;
+        const int strip = strip_raw < mg.nstrips ? strip_raw : mg.nstrips - 1;
+        const int seg = LOCK ? item / ngroups : item / mg.nstrips;
         const int iraw = strip * 62 - 1 + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
         const size_t colo = (size_t)(cvalid ? col : 0) + CO;
-        const bool out = lane >= 1 && lane < 63 && iraw < g.ni;
+        const bool out = lane >= 1 && lane < 63 && iraw < g.ni && strip_raw < mg.nstrips;
         const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
         double pa = 0.0, pb = 0.0, pc, po_b = 0.0, po_c;
         double d_b = 1.0, cw_b = 0.0, ce_b = 0.0, cs_b = 0.0, cn_b = 0.0;
@@ -2736,13 +2790,19 @@ __global__ __launch_bounds__(256) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df
             pa = pb; pb = pc; po_b = po_c; xv_b = xv_c;
             d_b = d_c; cw_b = cw_c; ce_b = ce_c; cs_b = cs_c; cn_b = cn_c;
             cell_b = cc;
+            if (LOCK) __syncthreads();       // same j0, j1 for every wave of the workgroup: uniform trip count
         }
     }
-    __shared__ double sm[4];
+    __shared__ double sm[WPB];
     const double w = wsum(dot);
     if (lane == 0) sm[wave] = w;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q4 = 0; q4 < WPB; q4 += 4) tot += (sm[q4] + sm[q4 + 1]) + (sm[q4 + 2] + sm[q4 + 3]);
+        partials[blockIdx.x] = tot;
+    }
 }
 // r -= alpha q ; partial = (r, r)
 __global__ void k_cg_r(Geo g, Tiling T, const CgScal *s, int gen, const double *q, double *r, double *partials, int nts) {
@@ -2808,7 +2868,9 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     MarchGeo mgeo = march_geo(g);
     mgeo.nstrips = (g.ni + 61) / 62;
     mgeo.xcd = c->xcd_map;
-    const dim3 mgrid(march_blocks(mgeo));
+    // lockstep workgroups of 8 / 16 neighbouring strips on meshes wide enough to fill them
+    const int wide = march_wide(c, mgeo, WIDE_CG_PQ);
+    const dim3 mgrid(march_grid(mgeo, wide));
     CFD_HIP(hipMemsetAsync(S, 0, sizeof(CgScal), st));
     if (fused) {
         // the right-hand side plane is a work plane of the caller: it becomes the residual in place, and
@@ -2878,8 +2940,12 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             p = pbuf[gen];
             CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
             c->probe_begin(0);
-            hipLaunchKernelGGL(k_cg_pq, mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, it == 1, z, pold, p, q, x, c->partials,
-                               c->nts(g));
+            if (wide == 8)
+                hipLaunchKernelGGL((k_cg_pq<8>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, it == 1, z, pold, p, q, x,
+                                   c->partials, c->nts(g));
+            else
+                hipLaunchKernelGGL((k_cg_pq<4>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, it == 1, z, pold, p, q, x,
+                                   c->partials, c->nts(g));
             // algorithmic bytes: z, c_i, c_j read, p', q written (40); + p_old from the second step (48 -> with the x store 56);
             // + the x read from the third (64)
             c->probe_end(0, it == 0 ? 40.0 : (it == 1 ? 56.0 : 64.0));

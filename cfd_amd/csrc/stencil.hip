@@ -482,7 +482,21 @@ constexpr int FXW = 62;
 
 struct FluxMarch {
     int nstrips, nsegs, Ls, blocks;
+    int wide = 4;        // 8: lockstep workgroups (blocks counts those)
 };
+constexpr int WIDE_FLUX = 128;       // Ctx::wide_mask bit of the flux kernels
+// lockstep form for the momentum / pressure right-hand-side passes on meshes with enough strips
+static inline void flux_march_widen(const Ctx *c, FluxMarch &m) {
+    if (!(c->wide_mask & WIDE_FLUX) || m.nstrips < 16) return;
+    m.wide = 8;
+    const long nb = (long)((m.nstrips + 7) / 8) * m.nsegs;
+    m.blocks = (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
+}
+#define LAUNCH_FLUX(fm, K4, K8, ...)                                                                        \
+    do {                                                                                                    \
+        if ((fm).wide == 8) hipLaunchKernelGGL(K8, dim3((fm).blocks), dim3(512), 0, c->stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(K4, dim3((fm).blocks), dim3(256), 0, c->stream, __VA_ARGS__);               \
+    } while (0)
 static inline FluxMarch flux_march_geo(const Geo &g) {
     FluxMarch m;
     m.nstrips = (g.ni + FXW - 1) / FXW;
@@ -516,20 +530,23 @@ struct MomArgs {
     int nts;                       // nontemporal stores of the right-hand side planes (store_stream)
 };
 
-template <int MODE, bool KG, bool DT = false>
-__global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, FluxMarch fm, MomArgs ma, double *bout,
-                                                    double *partials) {
+// WPB = 8: lockstep workgroups of eight neighbouring strips (MarchItems, internal.h)
+template <int MODE, bool KG, bool DT = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxIn f, FluxMarch fm, MomArgs ma, double *bout,
+                                                         double *partials) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
-    const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
     const int rc = MODE == 3 ? 0 : f.rc;
     double acc = MODE == 3 ? INFINITY : 0.0, acc2 = INFINITY, acc3 = INFINITY;
-    for (int item = blockIdx.x * 4 + wave; item < fm.nstrips * fm.nsegs; item += nw) {
-        const int strip = item % fm.nstrips, seg = item / fm.nstrips;
+    const MarchItems<WPB> items(fm.nstrips, fm.nsegs, 0, wave);
+    for (int item = items.first; item < items.count; item += items.stride) {
+        int strip, seg;
+        bool active;
+        items.decode(item, fm.nstrips, wave, strip, seg, active);
         const int iraw = strip * FXW - 1 + lane;          // -1 .. ni : ghost columns included
         const int ic = iraw < g.ni ? iraw : g.ni;
         const size_t colo = (size_t)(ic + CO);
-        const bool out = lane >= 1 && lane <= FXW && iraw < g.ni;
+        const bool out = lane >= 1 && lane <= FXW && iraw < g.ni && active;
         const bool ilo = iraw == 0, ihi = iraw == g.ni;
         const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
         auto fetch = [&](int j, FluxRow &R) {
@@ -766,28 +783,35 @@ __global__ __launch_bounds__(256) void k_flux_march(Geo g, MeshDev m, FluxIn f, 
             fw_p = fw_c; fs_p = fs_c;
             lw_p = lw_c; ls_p = ls_c;
             prv = cur;
+            if (WPB > 4) __syncthreads();       // lockstep: j0, j1 depend on the segment only
         }
     }
+    auto min_waves = [](const double *a) {
+        double r = a[0];
+#pragma unroll
+        for (int q = 1; q < WPB; ++q) r = fmin(r, a[q]);
+        return r;
+    };
     if (MODE == 3) {
-        __shared__ double sa[4], sb[4];
+        __shared__ double sa[WPB], sb[WPB];
         const double wa = wave_min(acc), wb = wave_min(acc2);
         if (lane == 0) { sa[wave] = wa; sb[wave] = wb; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            partials[blockIdx.x] = fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3]));
-            partials[MAX_PARTIALS + blockIdx.x] = fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3]));
+            partials[blockIdx.x] = min_waves(sa);
+            partials[MAX_PARTIALS + blockIdx.x] = min_waves(sb);
         }
     } else {
-        __shared__ double sm[4], sa[4], sb[4];
+        __shared__ double sm[WPB], sa[WPB], sb[WPB];
         const double w = wave_sum(acc);
         const double wa = DT ? wave_min(acc2) : 0.0, wb = DT ? wave_min(acc3) : 0.0;
         if (lane == 0) { sm[wave] = w; if (DT) { sa[wave] = wa; sb[wave] = wb; } }
         __syncthreads();
         if (threadIdx.x == 0) {
-            partials[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+            partials[blockIdx.x] = sum_waves<WPB>(sm);
             if (DT) {
-                partials[MAX_PARTIALS + blockIdx.x] = fmin(fmin(sa[0], sa[1]), fmin(sa[2], sa[3]));
-                partials[2 * MAX_PARTIALS + blockIdx.x] = fmin(fmin(sb[0], sb[1]), fmin(sb[2], sb[3]));
+                partials[MAX_PARTIALS + blockIdx.x] = min_waves(sa);
+                partials[2 * MAX_PARTIALS + blockIdx.x] = min_waves(sb);
             }
         }
     }
@@ -918,7 +942,8 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
     if (c->march_flux) {
         // marching kernel: the continuity sum of the same fluxes comes for free (cont != nullptr reads it)
-        const FluxMarch fm = flux_march_geo(c->g);
+        FluxMarch fm = flux_march_geo(c->g);
+        flux_march_widen(c, fm);
         MomArgs ma{c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j, c->bu, c->bv};
         ma.nts = c->nts();
         c->kc[KC_FLUX_MARCH] += 1;
@@ -934,22 +959,22 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
             ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
             ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
             if (c->turbulent)
-                hipLaunchKernelGGL((k_flux_march<2, true, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
-                                   (double *)nullptr, c->partials);
+                LAUNCH_FLUX(fm, (k_flux_march<2, true, true>), (k_flux_march<2, true, true, 8>), c->g, c->mesh(), f, fm, ma,
+                            (double *)nullptr, c->partials);
             else
-                hipLaunchKernelGGL((k_flux_march<2, false, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
-                                   (double *)nullptr, c->partials);
+                LAUNCH_FLUX(fm, (k_flux_march<2, false, true>), (k_flux_march<2, false, true, 8>), c->g, c->mesh(), f, fm, ma,
+                            (double *)nullptr, c->partials);
             hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials + MAX_PARTIALS, fm.blocks, 2,
                                c->scal + DT_AHEAD_OFF);
             c->dt_ahead = true;
             c->dt_ahead_diff = !c->turbulent;
             c->dt_ahead_cur = c->cur;
         } else if (c->turbulent) {
-            hipLaunchKernelGGL((k_flux_march<2, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
-                               (double *)nullptr, c->partials);
+            LAUNCH_FLUX(fm, (k_flux_march<2, true>), (k_flux_march<2, true, false, 8>), c->g, c->mesh(), f, fm, ma,
+                        (double *)nullptr, c->partials);
         } else {
-            hipLaunchKernelGGL((k_flux_march<2, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
-                               (double *)nullptr, c->partials);
+            LAUNCH_FLUX(fm, (k_flux_march<2, false>), (k_flux_march<2, false, false, 8>), c->g, c->mesh(), f, fm, ma,
+                        (double *)nullptr, c->partials);
         }
         CFD_HIP(hipGetLastError());
         if (cont) return finish_continuity(c, fm.blocks, cont, dt_too);
@@ -1113,13 +1138,13 @@ __global__ void k_ns_rhs(Geo g, int pi, int pj, const double *total, double *b) 
 int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b) {
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
     if (c->march_flux) {
-        const FluxMarch fm = flux_march_geo(c->g);
+        FluxMarch fm = flux_march_geo(c->g);
+        flux_march_widen(c, fm);
         MomArgs ma{};
         ma.nts = c->nts();
         c->kc[KC_FLUX_MARCH] += 1;
         if (fm.nstrips > 1) c->kc[KC_FLUX_MARCH_MULTISTRIP] += 1;
-        hipLaunchKernelGGL((k_flux_march<1, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma, b,
-                           c->partials);
+        LAUNCH_FLUX(fm, (k_flux_march<1, false>), (k_flux_march<1, false, false, 8>), c->g, c->mesh(), f, fm, ma, b, c->partials);
     } else {
         hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
     }
@@ -1128,7 +1153,9 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
         // singular (nullspace) form: every row is kept; the reference cell's row -- the one the reference
         // replaces -- absorbs the global imbalance, b_ref -= sum(b), so that the system is compatible
         if (c->march_flux) {
-            c->n_red_blocks = flux_march_geo(c->g).blocks;
+            FluxMarch fm = flux_march_geo(c->g);
+            flux_march_widen(c, fm);
+            c->n_red_blocks = fm.blocks;
         } else {
             int tx;
             const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);

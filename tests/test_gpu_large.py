@@ -336,3 +336,40 @@ def test_graded_komega_channel_against_oracle(tmp_path):
     last = hip_solver.LAST_RUN
     assert last["kernel_counts"]["mg_line_levels_max"] >= 3 and last["stats"]["p_unconverged"] == 0, last
     assert last["stats"]["p_iters"] <= 40, last["stats"]           # rtol 1e-13; point Jacobi needs > 150 here
+
+
+@pytest.mark.parametrize("turbulent", [False, True])
+def test_lockstep_workgroups_match_independent_waves(turbulent, tmp_path):
+    """Marching kernels as lockstep workgroups of 8 (or 4) neighbouring strips (tuning wide_mask, the default on meshes
+    of >= 16 strips) against the independent-wave forms on a 1024 x 64 channel: same iteration counts, fields equal to
+    rounding (the workgroup sums of the inner products are taken in another order)."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    runs = {}
+    for mask in (0, 411, 511):
+        cfg, mp, kind = cases.channel_forced(n=64, steps=3, turbulent=turbulent, ratio_j=1.0)
+        mp.update({"count_i": 1024, "length_i": 16.0 * mp["length_i"]})
+        for side, n in (("i_min", 64), ("i_max", 64), ("j_min", 1024), ("j_max", 1024)):
+            cfg["boundary"][side]["range"] = (0, n - 1)
+        work = tmp_path / f"m{mask}"
+        cfg["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp, "path": work / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": work, "mesh_dir": work / "mesh", "states_dir": work / "states", "post_dir": work / "postproc"}
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        cases.perturbed_parabola(cfg, mesh)
+        cfg["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
+        cfg["solver"]["momentum"]["tol"] = TRANSPORT_TOL
+        cfg["solver"]["tuning"] = {"mg_line": 0, "wide_mask": mask}
+        fields, step, time = hip_solver.run_case(cfg)
+        log = np.loadtxt(work / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+        runs[mask] = (fields, log, dict(hip_solver.LAST_RUN))
+    base = runs[0]
+    assert base[2]["kernel_counts"]["cheb4_2rhs"] > 0 and base[2]["kernel_counts"]["cg_pq"] > 0
+    for mask in (411, 511):
+        fields, log, last = runs[mask]
+        for key in base[0]:
+            if key == "p_corr":
+                continue
+            assert rel_l2(mask_corners(fields[key]), mask_corners(base[0][key])) < FIELD_TOL, (mask, key)
+        assert np.array_equal(log[:, 2], base[1][:, 2])
+        assert np.all(np.abs(log[:, 3] - base[1][:, 3]) <= 1e-9 * base[1][:, 3] + 1e-14)
+        assert last["stats"]["p_iters"] == base[2]["stats"]["p_iters"]
