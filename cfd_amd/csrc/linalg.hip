@@ -2952,7 +2952,8 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             c->kc[KC_CG_PQ] += 1;
             CFD_HIP(hipGetLastError());
             CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));
-            if (can_defer && it + 3 < c->p_iters_hint && it + 1 < maxiter) {
+            // (lagged host reads look at |r| of the expected last iteration and the one before it only)
+            if (can_defer && it + (c->host_lag ? 2 : 3) < c->p_iters_hint && it + 1 < maxiter) {
                 deferred = true;               // the next V-cycle forms r itself; nobody reads |r| of this iteration
                 deferred_gen = gen;
                 ++it;
@@ -2972,13 +2973,12 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         CFD_HIP(hipGetLastError());
         ++it;
         // The host looks at |r| (one stream synchronisation, during which the GPU idles) first at the count the
-        // previous solve with this frozen operator needed.  The two iterations before it leave their |r|^2 in
-        // device slots that the same read brings along: had one of them met the test already, the next solve
-        // expects that count (this one has then iterated one or two times more than it had to; the stopping
-        // test itself is unchanged).  Earlier iterations leave their partial sums of (r, r) unreduced (one small
+        // previous solve with this frozen operator needed.  The iteration before it leaves its |r|^2 in a
+        // device slot that the same read brings along: had it met the test already, the next solve expects that
+        // count (this one has then iterated once more than it had to; the stopping test itself is unchanged).  Earlier iterations leave their partial sums of (r, r) unreduced (one small
         // kernel and, on j-slabs, one all-reduce less).
         if (c->host_lag) {
-            if (it + 2 < hint0 && it < maxiter) continue;
+            if (it + 1 < hint0 && it < maxiter) continue;
             CFD_TRY(finish_to(c, T.blocks, 1, RR_HIST_OFF + (it & 7)));
             if (it < hint0 && it < maxiter) continue;
             double hist[8];
@@ -2989,7 +2989,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             if (sqrt(rr) <= tol * sqrt(bb)) {
                 converged_at = it;
                 if (it == hint0)
-                    for (int k = it - 1; k >= 1 && k + 2 >= hint0; --k)
+                    for (int k = it - 1; k >= 1 && k + 1 >= hint0; --k)
                         if (sqrt(hist[k & 7]) <= tol * sqrt(bb)) converged_at = k;
                 break;
             }
