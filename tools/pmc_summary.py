@@ -31,6 +31,27 @@ ALGO = {"k_chebk<2, 4, 2>": 98.7, "k_chebk<1, 4, 2>": 64, "k_chebk<2, 4, 1>": 98
 KNOWN_READS = {"k_cg_r": 16.0, "k_cg_xlast": 16.0, "k_cg_init": 8.0}      # calibration kernels
 
 
+def algo_of(k):
+    """algorithmic bytes per cell of a kernel name, template arguments of the lockstep forms ignored"""
+    if k in ALGO:
+        return ALGO[k]
+    m = re.match(r"k_chebk<(\d), 4", k)
+    if m:
+        return 98.7 if m.group(1) == "2" else 64
+    if k.startswith("k_cg_pq<"):
+        return 58
+    if k.startswith("k_mg_up_k<true, 3"):
+        return 42
+    m = re.match(r"k_mg_down_k<true, 3, (true|false)", k)
+    if m:
+        return 50 if m.group(1) == "true" else 34
+    m = re.match(r"k_flux_march<(\d), (true|false)(?:, (true|false))?", k)
+    if m:
+        mode, kg, dt = m.group(1), m.group(2) == "true", m.group(3) == "true"
+        return {"0": 104, "1": 112, "2": 120, "3": 88, "4": 144}[mode] + (8 if (mode == "2" and (kg or dt)) else 0)
+    return None
+
+
 def short(name):
     m = re.search(r"cfd::(k_\w+(?:<[^>]*>)?)", name)
     return m.group(1) if m else name.split("(")[0]
@@ -77,12 +98,13 @@ with open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv", "w") as f:
     f.write("# kernels with known reads, fetched / algorithmic read bytes: " + ", ".join(f"{k} {v:.3f}" for k, v in known.items()) + "\n")
     f.write(f"# avg_us / share from profiles/{tag}_bench8192_kernel_stats.csv (rocprofv3 --kernel-trace --stats of bench.py --steps 10 --warmup 3).\n")
     f.write("kernel;total_B_per_cell;fetch_B_per_cell;write_B_per_cell;algorithmic_B_per_cell;ratio;avg_us;share_pct;launches;algorithmic_TBps\n")
-    for k in sorted(ALGO, key=lambda k: -(stats.get(k, (0, 0))[1])):
-        if k not in ft or k not in stats:
+    for k in sorted(ft, key=lambda k: -(stats.get(k, (0, 0))[1])):
+        a = algo_of(k)
+        if a is None or k not in stats:
             continue
         fr = ft[k] / fc[k] * 1024.0 * FACTOR / cells
         wr = wt.get(k, 0.0) / max(wc.get(k, 1), 1) * 1024.0 / cells
         us, share = stats[k]
-        f.write(";".join([k, f"{fr + wr:.2f}", f"{fr:.2f}", f"{wr:.2f}", f"{ALGO[k]}", f"{(fr + wr) / ALGO[k]:.3f}", f"{us:.1f}", f"{share:.2f}",
-                          str(fc[k]), f"{ALGO[k] * cells / us / 1e6:.2f}"]) + "\n")
+        f.write(";".join([k, f"{fr + wr:.2f}", f"{fr:.2f}", f"{wr:.2f}", f"{a}", f"{(fr + wr) / a:.3f}", f"{us:.1f}", f"{share:.2f}",
+                          str(fc[k]), f"{a * cells / us / 1e6:.2f}"]) + "\n")
 print(open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv").read())
