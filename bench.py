@@ -301,6 +301,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from cfd_amd import _lib as L
     from cfd_amd.solver import advance_one_step
 
     n = args.size
@@ -327,31 +328,16 @@ def main():
                           omegas=[float(v) for v in args.mg_omegas.split(",")] if args.mg_omegas else None)
     step = 0
     iters = []
-    # ---- which hot kernel has the largest share of device time?  One untimed step per candidate with the event-pair
-    # probe on it (these steps also serve as extra warm-up); the winner is probed inside the timed region.
+    # ---- the event-pair probe runs on EVERY hot kernel inside the timed region (cfd_probe(CFD_PROBE_ALL): two event
+    # records per launch, about sixty launches per step); afterwards the kernel with the largest share of the probed
+    # device time is the `roofline` kernel and the others are reported beside it, all from the timed steps themselves
     shares = {}
     probe_id = args.probe
-    if probe_id < 0:
-        advance_one_step(dev, ctl, step)      # first step: operators are built, nothing is representative yet
-        step += 1
-        for pid in CANDIDATES:
-            dev.probe(pid)
-            advance_one_step(dev, ctl, step)
-            step += 1
-            dev.synchronize()
-            cnt, us = dev.probe_read()
-            dev.probe(-1)
-            shares[pid] = cnt * us
-        probe_id = max(shares, key=shares.get)
-        if world > 1:      # every rank must probe the same kernel (it does not change the collectives, only the events)
-            t = torch.tensor([probe_id], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.int64)
-            dist.broadcast(t, 0)
-            probe_id = int(t.item())
     for _ in range(args.warmup):
         info = advance_one_step(dev, ctl, step)
         step += 1
     dev.synchronize()
-    dev.probe(probe_id)
+    dev.probe(L.PROBE_ALL if probe_id < 0 else probe_id)
     comm0 = dev.comm_counts()
     phase0 = dev.comm_counts_by_phase()
     barrier()
@@ -368,7 +354,15 @@ def main():
         t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_probe, probe_us, probe_bpc = dev.probe_read(with_bytes=True)
+    per_kernel = {}
+    if probe_id < 0:
+        for pid in CANDIDATES:
+            per_kernel[pid] = dev.probe_read(with_bytes=True, kernel=pid)
+            shares[pid] = per_kernel[pid][0] * per_kernel[pid][1]
+        probe_id = max(shares, key=shares.get)
+        n_probe, probe_us, probe_bpc = per_kernel[probe_id]
+    else:
+        n_probe, probe_us, probe_bpc = dev.probe_read(with_bytes=True)
     dev.probe(-1)
     comm1, phase1 = dev.comm_counts(), dev.comm_counts_by_phase()
     # ---- outside the timed region: per-phase device times of two more steps (event pairs with a host
@@ -388,6 +382,9 @@ def main():
     others = {}
     for pid in CANDIDATES:
         if pid == probe_id:
+            continue
+        if pid in per_kernel:            # timed inside the timed region together with the headline kernel
+            others[pid] = per_kernel[pid]
             continue
         dev.probe(pid)
         advance_one_step(dev, ctl, step)

@@ -19,6 +19,7 @@ F_SST_S, F_SST_F1, F_SST_F2, F_SST_DK, F_SST_DW, F_SST_DWALL = range(12, 18)
 F_U_PREV, F_V_PREV, F_P_PREV = 18, 19, 20       # snapshot planes (u_prev, v_prev, p_prev of correct_velocity)
 TURB_KOMEGA, TURB_SST = 0, 1
 KIND_GHOSTED, KIND_CELL, KIND_FACE_I, KIND_FACE_J = range(4)
+PROBE_ALL = 1000        # CFD_PROBE_ALL of include/cfd_hip.h
 RCCL_ID_BYTES = 128     # CFD_RCCL_ID_BYTES of include/cfd_hip.h
 GHOST_ROWS = 4          # CFD_GHOST_ROWS of include/cfd_hip.h (checked against cfd_ghost_rows() when the library loads)
 SIDE_IMIN, SIDE_IMAX, SIDE_JMIN, SIDE_JMAX = range(4)
@@ -116,6 +117,7 @@ SIGNATURES = {
     "cfd_time_kernel": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "cfd_probe": (C.c_int, [_vp, C.c_int]),
     "cfd_probe_read": (C.c_int, [_vp, C.POINTER(C.c_int), _dp, _dp]),
+    "cfd_probe_read_id": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), _dp, _dp]),
     "cfd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "cfd_host_counters": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "cfd_kernel_counts": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.c_int, C.c_int]),

@@ -1324,10 +1324,14 @@ int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, in
 int cfd_probe(cfd_ctx *ctx, int kernel) {
     CTX(ctx);
     CFD_HIP(hipStreamSynchronize(c->stream));
-    if (kernel >= 0 && c->probe_e0.empty()) {
-        c->probe_e0.resize(4096);
-        c->probe_e1.resize(4096);
-        for (size_t q = 0; q < c->probe_e0.size(); ++q) {
+    const size_t want = kernel == CFD_PROBE_ALL ? 16384 : 4096;
+    if (kernel >= 0 && c->probe_e0.size() < want) {
+        const size_t have = c->probe_e0.size();
+        c->probe_e0.resize(want);
+        c->probe_e1.resize(want);
+        c->probe_id.resize(want);
+        c->probe_b.resize(want);
+        for (size_t q = have; q < want; ++q) {
             CFD_HIP(hipEventCreate(&c->probe_e0[q]));
             CFD_HIP(hipEventCreate(&c->probe_e1[q]));
         }
@@ -1338,20 +1342,29 @@ int cfd_probe(cfd_ctx *ctx, int kernel) {
     return CFD_OK;
 }
 
-int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us, double *avg_bytes_per_cell) {
+// kernel < 0: every timed launch
+int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, double *avg_bytes_per_cell) {
     CTX(ctx);
     if (!count || !avg_us) return CFD_E_ARG;
-    if (avg_bytes_per_cell) *avg_bytes_per_cell = c->probe_n ? c->probe_bytes / c->probe_n : 0.0;
     CFD_HIP(hipStreamSynchronize(c->stream));
-    double tot = 0.0;
+    double tot = 0.0, bytes = 0.0;
+    int n = 0;
     for (int q = 0; q < c->probe_n; ++q) {
+        if (kernel >= 0 && c->probe_id[q] != kernel) continue;
         float ms = 0.f;
         CFD_HIP(hipEventElapsedTime(&ms, c->probe_e0[q], c->probe_e1[q]));
         tot += ms;
+        bytes += c->probe_b[q];
+        ++n;
     }
-    *count = c->probe_n;
-    *avg_us = c->probe_n ? 1000.0 * tot / c->probe_n : 0.0;
+    *count = n;
+    *avg_us = n ? 1000.0 * tot / n : 0.0;
+    if (avg_bytes_per_cell) *avg_bytes_per_cell = n ? bytes / n : 0.0;
     return CFD_OK;
+}
+
+int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us, double *avg_bytes_per_cell) {
+    return cfd_probe_read_id(ctx, -1, count, avg_us, avg_bytes_per_cell);
 }
 
 int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us) {

@@ -395,18 +395,23 @@ struct Ctx {
     bool dt_host_valid = false;  // h_dt_ahead holds the (globally reduced) minima the last cont pass computed ahead
     double h_dt_ahead[2] = {0.0, 0.0};
 
-    // live kernel probe (bench.py): HIP-event pairs around every launch of one kernel id
+    // live kernel probe (bench.py): HIP-event pairs around every launch of one kernel id, or (CFD_PROBE_ALL) of every id
     int probe_kernel = -1;
     std::vector<hipEvent_t> probe_e0, probe_e1;
+    std::vector<int> probe_id;
+    std::vector<double> probe_b;  // algorithmic bytes per cell of each timed launch (they differ per launch)
     int probe_n = 0;
-    double probe_bytes = 0.0;     // algorithmic bytes per cell summed over the timed launches (they differ per launch)
+    double probe_bytes = 0.0;
     double last_rhs_bytes = 0.0;  // algorithmic bytes per cell of the last momentum right-hand side launch
+    inline bool probing(int id) const { return (id == probe_kernel || probe_kernel == CFD_PROBE_ALL) && probe_n < (int)probe_e0.size(); }
     inline void probe_begin(int id) {
-        if (id == probe_kernel && probe_n < (int)probe_e0.size()) (void)hipEventRecord(probe_e0[probe_n], stream);
+        if (probing(id)) (void)hipEventRecord(probe_e0[probe_n], stream);
     }
     inline void probe_end(int id, double bytes_per_cell = 0.0) {
-        if (id == probe_kernel && probe_n < (int)probe_e0.size()) {
+        if (probing(id)) {
             (void)hipEventRecord(probe_e1[probe_n], stream);
+            probe_id[probe_n] = id;
+            probe_b[probe_n] = bytes_per_cell;
             ++probe_n;
             probe_bytes += bytes_per_cell;
         }

@@ -408,10 +408,11 @@ class Device:
     def probe(self, kernel):
         check(self.lib.cfd_probe(self._h, int(kernel)))
 
-    def probe_read(self, with_bytes=False):
-        """(launches timed, mean duration in us[, mean algorithmic bytes per cell of those launches])."""
+    def probe_read(self, with_bytes=False, kernel=-1):
+        """(launches timed, mean duration in us[, mean algorithmic bytes per cell of those launches]); kernel >= 0: of that
+        kernel id alone (after probe(_lib.PROBE_ALL))."""
         n, us, bpc = C.c_int(), C.c_double(), C.c_double()
-        check(self.lib.cfd_probe_read(self._h, C.byref(n), C.byref(us), C.byref(bpc)))
+        check(self.lib.cfd_probe_read_id(self._h, int(kernel), C.byref(n), C.byref(us), C.byref(bpc)))
         return (n.value, us.value, bpc.value) if with_bytes else (n.value, us.value)
 
     def level_smoothers(self):

@@ -383,11 +383,14 @@ int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us);
  * kernel while the solver runs, up to 4096 launches (-1 = off): 0 = PCG direction step, 1 = finest-level
  * multigrid pre-smoother pass, 10 = the same with the PCG residual update folded in, 7 = post-smoother pass,
  * 2 = momentum right-hand sides (+ continuity, + time-step minima), 8 / 9 = Chebyshev launches with two / one
- * right-hand sides.  cfd_probe_read returns how many launches were timed and their average duration.        */
+ * right-hand sides; CFD_PROBE_ALL = all of them at once, up to 16384 launches in all.  cfd_probe_read returns how many
+ * launches were timed and their average duration, cfd_probe_read_id the same for one kernel of a CFD_PROBE_ALL run.  */
+#define CFD_PROBE_ALL 1000
 int cfd_probe(cfd_ctx *ctx, int kernel);
 /* avg_bytes_per_cell (may be NULL): mean ALGORITHMIC bytes per cell of the timed launches -- they differ from launch to
  * launch for some kernels (the first two direction steps of a PCG solve skip the x / p_old planes: 40 / 56 / 64 B)  */
 int cfd_probe_read(cfd_ctx *ctx, int *count, double *avg_us, double *avg_bytes_per_cell);
+int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, double *avg_bytes_per_cell);
 /* Tuning / A-B switches of the kernel forms, for tests and measurements (results are the same bits either way unless
  * noted; the library reads no environment variable): "cheb_stages" (1 / 2 / 4 Chebyshev iterations per launch),
  * "cheb_prefetch" (1 / 2 rows of loads in flight per wave), "fuse_nut", "dt_lookahead", "fuse_resid" (0 / 1: the
