@@ -619,6 +619,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
     else if (n == "scalar_nu") { c->scalar_nu = iv ? 1 : 0; c->ap_cached = false; }
     else if (n == "host_lag") c->host_lag = iv ? 1 : 0;
+    else if (n == "mg_gamma") { if (!(value > 0.0 && value <= 2.0)) { set_error("mg_gamma: (0, 2]"); return CFD_E_ARG; } c->mg_gamma = value; }
+    else if (n == "mg_om0" || n == "mg_om1" || n == "mg_om2") { if (!(value > 0.0 && value <= 1.5)) { set_error("mg_om*: (0, 1.5]"); return CFD_E_ARG; } c->mg_om[n[5] - '0'] = value; }
     else if (n == "xcd_map") c->xcd_map = iv ? 1 : 0;
     else if (n == "wide_mask") { if (iv < 0 || iv > 511) { set_error("wide_mask: 0 .. 511"); return CFD_E_ARG; } c->wide_mask = iv; }
     else if (n == "mg_tail") { c->mg_tail = iv ? 1 : 0; c->p_built = false; }

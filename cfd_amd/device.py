@@ -215,11 +215,11 @@ class Device:
                                       float(turb_tol), int(turb_maxiter), int(bool(freeze_pressure))))
 
     def set_multigrid(self, nu_pre=3, nu_post=3, omega=None, coarse_sweeps=40, fused=True, omega2=None, omegas=None):
-        """omegas: list of 1-4 Jacobi damping factors used cyclically by the sweeps (default (1.0, 0.55, 0.9));
+        """omegas: list of 1-4 Jacobi damping factors used cyclically by the sweeps (default (1.25, 0.5, 1.0));
         omega / omega2: the older two-value form."""
         if omegas is None:
             if omega is None:
-                omegas = (1.0, 0.55, 0.9) if nu_pre == 3 else (1.0, 0.6)
+                omegas = (1.25, 0.5, 1.0) if nu_pre == 3 else (1.0, 0.6)
             else:
                 omegas = (omega,) if not omega2 else (omega, omega2)
         om = np.ascontiguousarray(omegas, dtype=np.float64)

@@ -271,7 +271,7 @@ def configure_device(dev, config, geometry, nu, turb_on):
                    pressure_cfg.get("tol", 1.0e-8), pressure_cfg.get("maxiter", 200),
                    turb_solver_cfg.get("tol", 1.0e-8), turb_solver_cfg.get("maxiter", 200),
                    pressure_cfg.get("freeze_operator", True))
-    if mg:       # otherwise the library defaults: V(3,3) with dampings (1.0, 0.55, 0.9)
+    if mg:       # otherwise the library defaults: V(3,3) with dampings (1.25, 0.5, 1.0)
         nu_default = 3
         dev.set_multigrid(mg.get("nu_pre", nu_default), mg.get("nu_post", nu_default), mg.get("omega"),
                           mg.get("coarse_sweeps", 40), mg.get("fused", True), mg.get("omega2"), mg.get("omegas"))

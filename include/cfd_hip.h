@@ -216,7 +216,7 @@ int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int c
  * smoother choice, solver.py:821-833.)                                                                  */
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
 /* General form: n = 1..4 damping factors in (0, 2), mean <= 1, used cyclically by the sweeps of a pass.
- * Default: V(3,3) with (1.0, 0.55, 0.9) (three sweeps fused per pass: 5 MG-PCG iterations per solve at
+ * Default: V(3,3) with (1.25, 0.5, 1.0) (three sweeps fused per pass: 5 MG-PCG iterations per solve at
  * 8192^2); j-slab contexts run the same kernels (a cut carries CFD_GHOST_ROWS halo rows).              */
 int cfd_set_smoother_omegas(cfd_ctx *ctx, int n, const double *omegas);
 /* Systems without any Dirichlet pressure (the reference pins one cell, solver.py:1033-1044):

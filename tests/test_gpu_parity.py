@@ -332,7 +332,7 @@ def _bc_variant(kind, ni, nj):
             "j_min": wall_j, "j_max": wall_j, "pressure_reference": {"cell": (0, 0), "value": 0.0}}
 
 
-@pytest.mark.parametrize("sweeps,omegas", [(2, (0.8,)), (2, (1.0, 0.6)), (3, (1.0, 0.55, 0.9))])
+@pytest.mark.parametrize("sweeps,omegas", [(2, (0.8,)), (2, (1.0, 0.6)), (3, (1.0, 0.55, 0.9)), (3, (1.25, 0.5, 1.0))])
 @pytest.mark.parametrize("kind,ni,nj", [("per_i", 64, 48), ("per_i", 130, 67), ("per_j", 33, 40), ("inout", 50, 37),
                                          ("inout", 257, 129)])
 def test_fused_vcycle_matches_unfused(kind, ni, nj, sweeps, omegas):

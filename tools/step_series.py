@@ -19,6 +19,6 @@ for step in range(steps):
     info = advance_one_step(dev, ctl, step)
     dev.synchronize()
     st = dev.stats()
-    rows.append((round(1e3 * (time.perf_counter() - t0), 2), st["p_iters"], st["mom_iters"]))
+    rows.append((round(1e3 * (time.perf_counter() - t0), 2), st["p_iters"], st["mom_iters"], float("%.3g" % st["p_relres"])))
 print(json.dumps({"tuning": tuning, "rows": rows}))
 dev.close()
