@@ -734,3 +734,52 @@ def test_pressure_nullspace_form_matches_pinned_cell(name, tmp_path):
             continue
         a, b = mask_corners(out[True][key]), mask_corners(out[False][key])
         assert np.linalg.norm((a - b).ravel()) <= 1e-9 * np.linalg.norm(b.ravel()) + 1e-12 * unorm, key
+
+
+def test_unconverged_solves_are_reported(tmp_path):
+    """A solve that stops at maxiter above its tolerance is never silent (the reference: bicgstab -> cg -> direct solve
+    for the transport systems, solver.py:809-818; RuntimeError from its pressure CG, solver.py:842-844):
+    transport solves return CFD_E_NOCONV after one restart with four times the budget; the pressure solve raises when
+    the operator is rebuilt every solve and counts (p_unconverged + RuntimeWarning of run_case) under the frozen one."""
+    import warnings
+    from cfd_amd import _lib as L
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+
+    def config(work):
+        cfg, mp, kind = cases.ALL_END_TO_END["channel_forced_24"][0]()
+        cfg["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp, "path": work / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": work, "mesh_dir": work / "mesh", "states_dir": work / "states", "post_dir": work / "postproc"}
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        fix = cases.ALL_END_TO_END["channel_forced_24"][1]
+        if fix is not None:
+            fix(cfg, mesh)
+        cfg["time"]["max_steps"] = 1
+        return cfg
+
+    # pressure, fresh operator every solve: error
+    cfg = config(tmp_path / "a")
+    cfg["solver"]["pressure"].update({"maxiter": 1, "tol": 1e-13, "freeze_operator": False})
+    with pytest.raises(L.HipError, match="Pressure solver did not converge"):
+        hip_solver.run_case(cfg)
+    # pressure, frozen operator: counted and warned about
+    cfg = config(tmp_path / "b")
+    cfg["solver"]["pressure"].update({"maxiter": 1, "tol": 1e-13, "freeze_operator": True})
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        hip_solver.run_case(cfg)
+    assert hip_solver.LAST_RUN["stats"]["p_unconverged"] > 0
+    assert any(issubclass(w.category, RuntimeWarning) and "pressure solve" in str(w.message) for w in seen)
+    # transport: a diffusion-dominated system (dt = 1e3) with a budget of one BiCGStab iteration, then four more
+    g = load_golden("func_annulus_12x16.npz")
+    mesh = golden_mesh(g)
+    nu, _ = (float(x) for x in g["params"])
+    dev = _device_for(mesh, FUNC_CASES["annulus_12x16"], nu)
+    dev.upload_fields({k: g[f"bc_{k}"].copy() for k in ("u", "v", "p", "k", "omega", "nu_t")})
+    dev.set_solver(1e-13, 1, 1e-13, 2000, 1e-13, 2000, True)
+    dev.set_transport_solver(False, False, 0.95, 80)
+    dev.momentum_diagonal(1.0e3, 1.0)
+    dev.momentum_rhs(1.0e3)
+    with pytest.raises(L.HipError, match="transport solve did not converge"):
+        dev.momentum_solve()
+    dev.close()
