@@ -619,6 +619,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
     else if (n == "scalar_nu") { c->scalar_nu = iv ? 1 : 0; c->ap_cached = false; }
     else if (n == "host_lag") c->host_lag = iv ? 1 : 0;
+    else if (n == "plane_swap") c->plane_swap = iv ? 1 : 0;
     else if (n == "mg_gamma") { if (!(value > 0.0 && value <= 2.0)) { set_error("mg_gamma: (0, 2]"); return CFD_E_ARG; } c->mg_gamma = value; }
     else if (n == "mg_om0" || n == "mg_om1" || n == "mg_om2") { if (!(value > 0.0 && value <= 1.5)) { set_error("mg_om*: (0, 1.5]"); return CFD_E_ARG; } c->mg_om[n[5] - '0'] = value; }
     else if (n == "xcd_map") c->xcd_map = iv ? 1 : 0;
@@ -1222,7 +1223,8 @@ int cfd_momentum_solve(cfd_ctx *ctx, double res[2]) {
     // the fine-grained API works in place on the current planes (like the reference): copy the interior
     for (int q = 0; q < 2; ++q) {
         double *dst = q == 0 ? c->U() : c->V();
-        CFD_HIP(hipMemcpy2DAsync(dst + c->g.at(1, 1), c->g.pitch * sizeof(double), x[q] + c->g.at(1, 1),
+        const double *src = q == 0 ? c->U1() : c->V1();       // (the solve may have rebound these planes: adopt_plane)
+        CFD_HIP(hipMemcpy2DAsync(dst + c->g.at(1, 1), c->g.pitch * sizeof(double), src + c->g.at(1, 1),
                                  c->g.pitch * sizeof(double), (size_t)c->g.ni * sizeof(double), c->g.nj,
                                  hipMemcpyDeviceToDevice, c->stream));
     }

@@ -1824,6 +1824,23 @@ struct ChebCoef {
     }
 };
 
+// The result of a solve sits in a Krylov work plane `where`, the caller expects it in the context plane `named`
+// (u*, v*, k, omega): instead of copying the plane, the two exchange roles -- the context's pointer is rebound to
+// `where` and the work-plane slot takes the old plane.  Same bits everywhere in the named plane as after a whole-plane
+// copy.  false: one of the two is not a plane the context can rebind (the caller copies).
+static bool adopt_plane(Ctx *c, double *named, double *where) {
+    double **slot = nullptr, **work = nullptr;
+    double **cand[6] = {&c->u[0], &c->u[1], &c->v[0], &c->v[1], &c->k, &c->omega};
+    for (double **p : cand)
+        if (*p == named) slot = p;
+    for (int q = 0; q < 16; ++q)
+        if (c->kry[q] == where) work = &c->kry[q];
+    if (!slot || !work) return false;
+    *work = named;
+    *slot = where;
+    return true;
+}
+
 template <int NB, int K>
 static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
                            double tol, int maxiter, int *iters, double relres[2], double rms[2], int *used) {
@@ -1873,9 +1890,21 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
     int kq[2] = {1, 1}, kdone[2] = {0, 0};
     int klimit = maxiter;
     auto conv = [&](int q, double r2) { return sqrt(r2) <= tol * sqrt(bb[q]); };
+    // where the result of a retired right-hand side waits (its planes are not touched by the launches that follow);
+    // it reaches x[q] when the solve ends: by rebinding the plane pointers (adopt_plane) when every right-hand side has
+    // converged here, by a copy when the solve goes on in BiCGStab, which works on the caller's x[q]
+    double *final_where[2] = {nullptr, nullptr};
+    auto deliver = [&](bool may_swap) -> int {
+        for (int q = 0; q < NB; ++q) {
+            if (!final_where[q] || final_where[q] == x[q]) continue;
+            if (!(may_swap && c->plane_swap && adopt_plane(c, x[q], final_where[q])))
+                CFD_HIP(hipMemcpyAsync(x[q], final_where[q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+            final_where[q] = nullptr;
+        }
+        return CFD_OK;
+    };
     auto retire = [&](int q, int k, double r2, double *where) -> int {
-        if (where != x[q])
-            CFD_HIP(hipMemcpyAsync(x[q], where, g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
+        final_where[q] = where;
         relres[q] = bb[q] > 0.0 ? sqrt(r2 / bb[q]) : 0.0;
         if (rms) rms[q] = sqrt(r2 / global_cells(c));
         act[q] = false;
@@ -2010,11 +2039,12 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                 *iters = std::max(kdone[0], kdone[NB - 1]);
                 *used = 1;
                 c->cheb_lag_ok = m >= 2 && !late_first;
-                return CFD_OK;
+                return deliver(true);
             }
             if (late_first) continue;                // now the sums of launch 2 itself, if it is time for them
             if (k0 + K - 1 >= klimit) {
                 // bound not met (spectrum outside the interval): hand the newest iterate to BiCGStab
+                CFD_TRY(deliver(false));
                 for (int q = 0; q < NB; ++q)
                     if (act[q] && set[m & 1][1][q] != x[q])
                         CFD_HIP(hipMemcpyAsync(x[q], set[m & 1][1][q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
