@@ -1319,6 +1319,7 @@ int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, in
     CFD_TRY(to_device(c, b, c->kry[11], CFD_KIND_CELL));
     int it = 0;
     double rr = 0;
+    c->bb_ready = false;
     CFD_TRY(pressure_solve(c, c->kry[11], c->kry[12], tol, maxiter, &it, &rr));
     if (iters) *iters = it;
     if (relres) *relres = rr;

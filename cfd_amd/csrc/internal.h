@@ -368,6 +368,7 @@ struct Ctx {
     // right-hand sides), 256 k_chebk with two right-hand sides as lockstep workgroups of FOUR strips (its 222 registers
     // allow two waves per SIMD either way).  Default: what measured faster at 8192^2.
     int wide_mask = 1 | 2 | 8 | 16 | 128 | 256;
+    bool bb_ready = false;       // scal[83] holds (b, b) of the pressure right-hand side just built (launch_pressure_rhs)
     int plane_swap = 1;          // the Chebyshev result plane becomes u* / v* / k / omega by rebinding pointers, not by a copy
     int mg_tail = 1;             // 1: levels that fit one workgroup's LDS are cycled by one launch
     int tail_lt = -1;            // first level of the tail (-1: none), set when the hierarchy is built

@@ -2906,13 +2906,21 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         // the right-hand side plane is a work plane of the caller: it becomes the residual in place, and
         // x = 0 is never stored (the first two direction steps and k_cg_xlast know it)
         r = const_cast<double *>(b);
-        CVecs<1> a1{{b}};
-        hipLaunchKernelGGL((k_dot<1>), grid, blk, 0, st, g, T, a1, a1, c->partials);
-    } else {
-        hipLaunchKernelGGL(k_cg_init, grid, blk, 0, st, g, T, b, r, x, c->partials);
     }
-    CFD_HIP(hipGetLastError());
-    CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(bb)));
+    if (fused && c->bb_ready) {
+        // the pass that built this right-hand side summed b^2 as well
+        CFD_HIP(hipMemcpyAsync(c->scal + CG_OFF_OF(bb), c->scal + 83, sizeof(double), hipMemcpyDeviceToDevice, st));
+    } else {
+        if (fused) {
+            CVecs<1> a1{{b}};
+            hipLaunchKernelGGL((k_dot<1>), grid, blk, 0, st, g, T, a1, a1, c->partials);
+        } else {
+            hipLaunchKernelGGL(k_cg_init, grid, blk, 0, st, g, T, b, r, x, c->partials);
+        }
+        CFD_HIP(hipGetLastError());
+        CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(bb)));
+    }
+    c->bb_ready = false;
     double bb = -1.0, rr = 0.0;
     *iters = 0;
     *relres = 0.0;

@@ -538,6 +538,7 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
     const size_t P = g.pitch;
     const int rc = MODE == 3 ? 0 : f.rc;
     double acc = MODE == 3 ? INFINITY : 0.0, acc2 = INFINITY, acc3 = INFINITY;
+    double accb = 0.0;       // MODE 1: sum b^2, the (b, b) the pressure solve starts from
     const MarchItems<WPB> items(fm.nstrips, fm.nsegs, 0, wave);
     for (int item = items.first; item < items.count; item += items.stride) {
         int strip, seg;
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                 const double vol = prv.vol;
                 const double div = (fe_p - fw_p + fs_c - fs_p) / vol;
                 if (MODE == 0) acc += div * div;
-                else { const double bv = vol * (-div); store_stream(bout + (size_t)(jo + NG) * P + colo, bv, ma.nts); acc += bv; }   // sum b (nullspace form)
+                else { const double bv = vol * (-div); store_stream(bout + (size_t)(jo + NG) * P + colo, bv, ma.nts); acc += bv; accb += bv * bv; }   // sum b (nullspace form), sum b^2
             }
             fw_p = fw_c; fs_p = fs_c;
             lw_p = lw_c; ls_p = ls_c;
@@ -804,11 +805,12 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
     } else {
         __shared__ double sm[WPB], sa[WPB], sb[WPB];
         const double w = wave_sum(acc);
-        const double wa = DT ? wave_min(acc2) : 0.0, wb = DT ? wave_min(acc3) : 0.0;
-        if (lane == 0) { sm[wave] = w; if (DT) { sa[wave] = wa; sb[wave] = wb; } }
+        const double wa = DT ? wave_min(acc2) : (MODE == 1 ? wave_sum(accb) : 0.0), wb = DT ? wave_min(acc3) : 0.0;
+        if (lane == 0) { sm[wave] = w; if (DT || MODE == 1) { sa[wave] = wa; sb[wave] = wb; } }
         __syncthreads();
         if (threadIdx.x == 0) {
             partials[blockIdx.x] = sum_waves<WPB>(sm);
+            if (MODE == 1) partials[MAX_PARTIALS + blockIdx.x] = sum_waves<WPB>(sa);
             if (DT) {
                 partials[MAX_PARTIALS + blockIdx.x] = min_waves(sa);
                 partials[2 * MAX_PARTIALS + blockIdx.x] = min_waves(sb);
@@ -1131,12 +1133,19 @@ __global__ void k_plane_sum(Geo g, const double *f, double *partials, int tiles_
     a = block_sum_256(a);
     if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = a;
 }
-__global__ void k_ns_rhs(Geo g, int pi, int pj, const double *total, double *b) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) b[g.cell(pi, pj)] -= total[0];
+// bb (may be null): (b, b) summed before this row changed; kept right by the difference of the two squares
+__global__ void k_ns_rhs(Geo g, int pi, int pj, const double *total, double *b, double *bb) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const size_t c = g.cell(pi, pj);
+        const double was = b[c], now = was - total[0];
+        b[c] = now;
+        if (bb) bb[0] += now * now - was * was;
+    }
 }
 
 int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *p, double *b) {
     FluxIn f{u, v, p, nullptr, c->ap, c->rhie_chow};
+    c->bb_ready = false;
     if (c->march_flux) {
         FluxMarch fm = flux_march_geo(c->g);
         flux_march_widen(c, fm);
@@ -1156,6 +1165,15 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
             FluxMarch fm = flux_march_geo(c->g);
             flux_march_widen(c, fm);
             c->n_red_blocks = fm.blocks;
+            if (c->comm.nranks == 1 && c->pin_i >= 0) {
+                // one rank: the marching pass also summed b^2, which saves the solve its first dot product (scal[83];
+                // on slabs the correction of the reference cell's row would have to travel, not worth a collective)
+                CFD_TRY(reduce_finish(c, 2, 82));
+                hipLaunchKernelGGL(k_ns_rhs, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->scal + 82, b, c->scal + 83);
+                CFD_HIP(hipGetLastError());
+                c->bb_ready = true;
+                return CFD_OK;
+            }
         } else {
             int tx;
             const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
@@ -1164,7 +1182,7 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
         }
         CFD_TRY(reduce_finish(c, 1, 80));               // scal[80] = sum over all slabs
         if (c->pin_i >= 0) {
-            hipLaunchKernelGGL(k_ns_rhs, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->scal + 80, b);
+            hipLaunchKernelGGL(k_ns_rhs, dim3(1), dim3(64), 0, c->stream, c->g, c->pin_i, c->pin_j, c->scal + 80, b, (double *)nullptr);
             CFD_HIP(hipGetLastError());
         }
         return CFD_OK;
