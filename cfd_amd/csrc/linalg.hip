@@ -2740,8 +2740,9 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 
 // Fused PCG direction step (marching, one halo lane / row):  p' = z + beta p ;  q = A p' ;  (p', q) ;
 // and the solution update of the PREVIOUS iteration, x += alpha_prev p, which reads the same p.
-// 72 B/cell (z, p, x, D, c_i, c_j read; p', q, x written) instead of 24 + 40 for k_cg_p + k_cg_q and
-// 16 of the 48 of k_cg_xr, whose remainder is k_cg_r below.  p' goes to a second plane: neighbouring
+// 64 B/cell on the finest level (z, p, x, c_i, c_j read; p', q, x written; D is recomputed from the face planes;
+// 40 / 56 B on the first / second step of a solve, which skip p / x), 72 B on levels that read a D plane, instead of
+// 24 + 40 for k_cg_p + k_cg_q and 16 of the 48 of k_cg_xr, whose remainder is k_cg_r below.  p' goes to a second plane: neighbouring
 // strips recompute p' on their halo from the old p.
 // WPB = 4: every wave takes work items (strip, segment) on its own.  WPB = 8 / 16 (lockstep form): a workgroup takes
 // WPB neighbouring strips of ONE segment and its waves meet at a barrier after every row, so that the workgroup reads

@@ -17,16 +17,19 @@ for n, turb in ((32, False), (64, False), (128, False), (256, False), (512, Fals
         step += 1
     dev.synchronize()
     dev.host_counters(reset=True)
-    t0 = time.perf_counter()
     k = 20
+    per_step = []
     for _ in range(k):
+        t0 = time.perf_counter()
         advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        per_step.append(1e3 * (time.perf_counter() - t0))
         step += 1
-    dev.synchronize()
-    ms = 1e3 * (time.perf_counter() - t0) / k
+    # median: one step in a few hundred stalls for tens of milliseconds on the box (host side, no kernel is that long)
+    ms = sorted(per_step)[k // 2]
     launches, syncs = dev.host_counters()
     st = dev.stats()
-    print(json.dumps({"n": n, "turbulent": turb, "ms_per_step": round(ms, 3), "cells_per_s": round(n * n / ms * 1e3),
-                      "launches_per_step": round(launches / k, 1), "syncs_per_step": round((syncs - 1) / k, 1),
+    print(json.dumps({"n": n, "turbulent": turb, "ms_per_step": round(ms, 3), "ms_mean": round(sum(per_step) / k, 3), "cells_per_s": round(n * n / ms * 1e3),
+                      "launches_per_step": round(launches / k, 1), "syncs_per_step": round((syncs - k) / k, 1),
                       "mom_iters": st["mom_iters"], "p_iters": st["p_iters"], "k_iters": st["k_iters"]}), flush=True)
     dev.close()
