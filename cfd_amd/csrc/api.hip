@@ -626,6 +626,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "wide_mask") { if (iv < 0 || iv > 511) { set_error("wide_mask: 0 .. 511"); return CFD_E_ARG; } c->wide_mask = iv; }
     else if (n == "mg_tail") { c->mg_tail = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
+    else if (n == "mg_line_dirs") { c->mg_line_dirs = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }
     else if (n == "mg_line_omega") { if (!(value > 0.0 && value <= 1.0)) { set_error("mg_line_omega: (0, 1]"); return CFD_E_ARG; } c->mg_line_omega = value; }
     else { set_error("cfd_set_option: unknown option '%s'", name); return CFD_E_ARG; }

@@ -198,7 +198,9 @@ struct Level {
     // alternating line smoother (levels whose face couplings are strongly anisotropic): factors of the tridiagonal
     // j-blocks (Thomas multipliers and inverse pivots), computed when the hierarchy is built
     bool line = false;
-    double *lm = nullptr, *linv = nullptr;
+    int line_dirs = 0;            // bit 0: j-lines, bit 1: i-lines
+    double *lm = nullptr, *linv = nullptr;        // j-blocks
+    double *lmi = nullptr, *linvi = nullptr;      // i-blocks
     double aniso = 1.0;           // max over the cells of strong / weak coupling (diagnostic, cfd_level_aniso)
 };
 
@@ -355,6 +357,7 @@ struct Ctx {
     char *line_mem = nullptr;      // Thomas factor planes of the line-smoothed multigrid levels (own allocation)
     size_t line_mem_bytes = 0;
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
+    int mg_line_dirs = 1;          // 1: a line-smoothed level sweeps both directions; 0: only those whose own coupling ratio exceeds the threshold (wall-graded 8192^2 channel: 79 iterations instead of 12, the wide centre cells need the i-lines)
     double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this
     double mg_line_omega = 0.8;
     // Contiguous-per-XCD block -> work item map of the marching kernels (A-B switch "xcd_map").  Measured at 8192^2: the

@@ -1255,12 +1255,13 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
 //       reduction over the 64 lanes (6 steps of wave shuffles), couplings across the block ends explicit.
 // Blocks are balanced (no short block at a wall, where the coupling is strongest).  CPU prototype and iteration
 // counts: tools/mg_proto_aniso.py.
-constexpr int LJ_MAX = 64;        // rows per j-block (LDS: 2 waves x 64 rows x 64 lanes x 8 B = 64 KiB per workgroup)
-constexpr int LJ_WAVES = 2;       // wavefronts per workgroup of k_line_j
+constexpr int LJ_MAX = 64;        // rows per j-block
 constexpr int LI_W = 62;          // cells per i-block
+constexpr int LJ_CHUNK = 8;       // rows whose loads k_line_j issues together
 
 struct LineGeo {
     int nstrips, wstrip, nsegs, Ls;
+    int nsegs_i, Ls_i;       // row segments of the i-line kernel (its rows are independent: a pure work split)
 };
 static inline LineGeo line_geo(const Geo &g) {
     LineGeo m;
@@ -1268,10 +1269,14 @@ static inline LineGeo line_geo(const Geo &g) {
     m.wstrip = (g.ni + m.nstrips - 1) / m.nstrips;
     m.nsegs = (g.nj + LJ_MAX - 1) / LJ_MAX;
     m.Ls = (g.nj + m.nsegs - 1) / m.nsegs;
+    int Li = 32;
+    while (Li > 4 && (long)m.nstrips * ((g.nj + Li - 1) / Li) < 8192) Li /= 2;
+    m.Ls_i = Li;
+    m.nsegs_i = (g.nj + Li - 1) / Li;
     return m;
 }
-static inline int line_blocks(const LineGeo &m, int waves = 4) {
-    const long nb = ((long)m.nstrips * m.nsegs + waves - 1) / waves;
+static inline int line_blocks(const LineGeo &m, bool iline = false) {
+    const long nb = ((long)m.nstrips * (iline ? m.nsegs_i : m.nsegs) + 3) / 4;
     return (int)(nb < 2 * MAX_PARTIALS ? nb : 2 * MAX_PARTIALS);
 }
 
@@ -1279,7 +1284,6 @@ static inline int line_blocks(const LineGeo &m, int waves = 4) {
 // of a block), linv = 1 / p_j.  One thread per column and block.
 __global__ void k_line_factor_j(OpDev op, LineGeo lg, double *lm, double *linv) {
     const Geo g = op.g;
-    const size_t P = g.pitch;
     const long n = (long)g.ni * lg.nsegs;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const int i = (int)(t % g.ni), seg = (int)(t / g.ni);
@@ -1294,7 +1298,25 @@ __global__ void k_line_factor_j(OpDev op, LineGeo lg, double *lm, double *linv) 
             linv[c] = 1.0 / pj;
             pprev = pj;
         }
-        (void)P;
+    }
+}
+// the same for the i-blocks (strips of wstrip cells): one thread per row and block
+__global__ void k_line_factor_i(OpDev op, LineGeo lg, double *lm, double *linv) {
+    const Geo g = op.g;
+    const long n = (long)g.nj * lg.nstrips;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(t % g.nj), strip = (int)(t / g.nj);
+        const int i0 = strip * lg.wstrip, i1 = min(i0 + lg.wstrip, g.ni);
+        double pprev = 1.0;
+        for (int i = i0; i < i1; ++i) {
+            const size_t c = g.cell(i, j);
+            const double cw = i > i0 ? op.ci[c] : 0.0;
+            const double m = i > i0 ? cw / pprev : 0.0;
+            const double pi = op.D[c] - m * cw;
+            lm[c] = m;
+            linv[c] = 1.0 / pi;
+            pprev = pi;
+        }
     }
 }
 
@@ -1320,15 +1342,21 @@ __global__ void k_level_aniso(OpDev op, Tiling T, double *partials) {
 }
 
 // One block j-line Jacobi sweep.  ZERO: the iterate is zero (first pre-smoothing sweep), xin is not read.
+// Lane = column; a wavefront marches down its block (forward elimination) and back up (substitution).  The
+// forward-eliminated right-hand sides wait in the OUTPUT plane itself: each lane re-reads, last row first, what it
+// stored a few microseconds earlier (L2 hits), so the kernel needs no LDS and no long register arrays and runs at
+// full occupancy (it held 32 KiB of LDS per wavefront before: five wavefronts per CU, 2.1 ms per sweep at 8192^2).
 template <bool ZERO>
-__global__ __launch_bounds__(64 * LJ_WAVES) void k_line_j(OpDev op, LineGeo lg, const double *lm, const double *linv, const double *b,
-                                                          const double *xin, double omega, double *xout) {
-    __shared__ double gl[LJ_WAVES][LJ_MAX][64];
+__global__ __launch_bounds__(256) void k_line_j(OpDev op, LineGeo lg, const double *__restrict__ lm, const double *__restrict__ linv,
+                                                const double *__restrict__ b, const double *__restrict__ xin, double omega,
+                                                double *__restrict__ xout) {
     const Geo g = op.g;
+    const double *__restrict__ ci = op.ci;
+    const double *__restrict__ cj = op.cj;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = gridDim.x * LJ_WAVES;
+    const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
-    for (int item = blockIdx.x * LJ_WAVES + wave; item < lg.nstrips * lg.nsegs; item += nw) {
+    for (int item = blockIdx.x * 4 + wave; item < lg.nstrips * lg.nsegs; item += nw) {
         const int strip = item % lg.nstrips, seg = item / lg.nstrips;
         const int iraw = strip * lg.wstrip - 1 + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
@@ -1343,93 +1371,153 @@ __global__ __launch_bounds__(64 * LJ_WAVES) void k_line_j(OpDev op, LineGeo lg, 
             return (cvalid && mr >= 0) ? xin[(size_t)mr * P + colo] : 0.0;
         };
         const double xlo = xrow(j0 - 1), xhi = xrow(j1);
+        // both passes take LJ_CHUNK rows at a time: all loads of a chunk are issued before its dependent chain runs
+        // (a coarse level has too few wavefronts to hide one memory latency per row)
         double gprev = 0.0;
-        for (int j = j0; j < j1; ++j) {
-            const size_t c = (size_t)(j + NG) * P + colo;
-            double rhs = b[c];
-            if (!ZERO) {
-                const double xc = cvalid ? xin[c] : 0.0;
-                const double xl = lane_left(xc), xr = lane_right(xc);
-                rhs += op.ci[c] * xl + op.ci[c + 1] * xr;
+        for (int jb = j0; jb < j1; jb += LJ_CHUNK) {
+            double vb[LJ_CHUNK], vm[LJ_CHUNK], vx[LJ_CHUNK], vw[LJ_CHUNK], ve[LJ_CHUNK];
+#pragma unroll
+            for (int k = 0; k < LJ_CHUNK; ++k) {
+                const size_t c = (size_t)(min(jb + k, j1 - 1) + NG) * P + colo;
+                vb[k] = b[c];
+                vm[k] = lm[c];
+                if (!ZERO) { vx[k] = cvalid ? xin[c] : 0.0; vw[k] = ci[c]; ve[k] = ci[c + 1]; }
             }
-            if (j == j0) rhs += op.cj[c] * xlo;
-            if (j == j1 - 1) rhs += op.cj[c + P] * xhi;
-            const double gj = rhs + lm[c] * gprev;
-            gl[wave][j - j0][lane] = gj;
-            gprev = gj;
+#pragma unroll
+            for (int k = 0; k < LJ_CHUNK; ++k) {
+                const int j = jb + k;
+                if (j < j1) {
+                    const size_t c = (size_t)(j + NG) * P + colo;
+                    double rhs = vb[k];
+                    if (!ZERO) {
+                        const double xl = lane_left(vx[k]), xr = lane_right(vx[k]);
+                        rhs += vw[k] * xl + ve[k] * xr;
+                    }
+                    if (j == j0) rhs += cj[c] * xlo;
+                    if (j == j1 - 1) rhs += cj[c + P] * xhi;
+                    const double gj = rhs + vm[k] * gprev;
+                    if (out) xout[c] = gj;
+                    gprev = gj;
+                }
+            }
         }
         double xnext = 0.0;
-        for (int j = j1 - 1; j >= j0; --j) {
-            const size_t c = (size_t)(j + NG) * P + colo;
-            const double cn = j < j1 - 1 ? op.cj[c + P] : 0.0;
-            const double xt = (gl[wave][j - j0][lane] + cn * xnext) * linv[c];
-            xnext = xt;
-            if (out) {
-                const double xo = ZERO ? 0.0 : xin[c];
-                xout[c] = xo + omega * (xt - xo);
+        for (int jb = j1 - 1; jb >= j0; jb -= LJ_CHUNK) {
+            double vg[LJ_CHUNK], vn[LJ_CHUNK], vi[LJ_CHUNK], vo[LJ_CHUNK];
+#pragma unroll
+            for (int k = 0; k < LJ_CHUNK; ++k) {
+                const size_t c = (size_t)(max(jb - k, j0) + NG) * P + colo;
+                vg[k] = xout[c];
+                vn[k] = cj[c + P];
+                vi[k] = linv[c];
+                vo[k] = ZERO ? 0.0 : xin[c];
+            }
+#pragma unroll
+            for (int k = 0; k < LJ_CHUNK; ++k) {
+                const int j = jb - k;
+                if (j >= j0) {
+                    const size_t c = (size_t)(j + NG) * P + colo;
+                    const double cn = j < j1 - 1 ? vn[k] : 0.0;
+                    const double xt = (vg[k] + cn * xnext) * vi[k];
+                    xnext = xt;
+                    if (out) xout[c] = vo[k] + omega * (xt - vo[k]);
+                }
             }
         }
     }
 }
 
-// One block i-line Jacobi sweep: parallel cyclic reduction over the 64 lanes of a wavefront.
+// One block i-line Jacobi sweep.  Lane = cell of the line: the two first-order recurrences of the Thomas algorithm
+// (elimination g_l = r_l + m_l g_{l-1}, substitution x_l = h_l + e_l x_{l+1}) are inclusive scans over the wavefront,
+// six DPP steps each (row_shr 1, 2, 4, 8, row_bcast 15, row_bcast 31; no LDS); the multipliers m and the inverse
+// pivots come from k_line_factor_i.  The substitution runs in mirrored lane order (lane l holds column 63 - l: its
+// operands are loaded mirrored, only the eliminated right-hand side crosses the lanes, by one ds_bpermute pair), so
+// that it is a forward scan too.  (The parallel cyclic reduction it replaces needed 96 ds_bpermute and seven
+// reciprocals per row: 3.8 ms per sweep at 8192^2.)
 __device__ __forceinline__ double shfl_from(double v, int src_lane) {
     const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_take(double keep, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ void scan_step(double &m, double &v) {
+    const double M = dpp_take<CTRL, ROWMASK>(1.0, m);       // lanes without a source keep the identity (1, 0)
+    const double V = dpp_take<CTRL, ROWMASK>(0.0, v);
+    v = v + m * V;
+    m = m * M;
+}
+// y_l = v_l + m_l y_{l-1} over the 64 lanes (y_{-1} = 0): returns y_l
+__device__ __forceinline__ double wave_recurrence(double m, double v) {
+    scan_step<0x111, 0xf>(m, v);        // row_shr:1
+    scan_step<0x112, 0xf>(m, v);        // row_shr:2
+    scan_step<0x114, 0xf>(m, v);        // row_shr:4
+    scan_step<0x118, 0xf>(m, v);        // row_shr:8
+    scan_step<0x142, 0xa>(m, v);        // row_bcast:15 into rows 1 and 3
+    scan_step<0x143, 0xc>(m, v);        // row_bcast:31 into rows 2 and 3
+    return v;
+}
 template <bool ZERO>
-__global__ __launch_bounds__(256) void k_line_i(OpDev op, LineGeo lg, const double *b, const double *xin, double omega,
-                                                double *xout) {
+__global__ __launch_bounds__(256) void k_line_i(OpDev op, LineGeo lg, const double *__restrict__ lm, const double *__restrict__ linv,
+                                                const double *__restrict__ b, const double *__restrict__ xin, double omega,
+                                                double *__restrict__ xout) {
     const Geo g = op.g;
+    const double *__restrict__ ci = op.ci;
+    const double *__restrict__ cj = op.cj;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = gridDim.x * 4;
     const size_t P = g.pitch;
-    for (int item = blockIdx.x * 4 + wave; item < lg.nstrips * lg.nsegs; item += nw) {
+    for (int item = blockIdx.x * 4 + wave; item < lg.nstrips * lg.nsegs_i; item += nw) {
         const int strip = item % lg.nstrips, seg = item / lg.nstrips;
+        const int nu = min(lg.wstrip, g.ni - strip * lg.wstrip);            // unknowns of this block: lanes 1 .. nu
         const int iraw = strip * lg.wstrip - 1 + lane;
         const int col = wrap_index(iraw, g.ni, op.per_i);
         const bool cvalid = col >= 0;
         const size_t colo = (size_t)(cvalid ? col : 0) + CO;
-        const bool act = lane >= 1 && lane <= lg.wstrip && iraw < g.ni;      // unknowns of this block
-        const int j0 = seg * lg.Ls, j1 = min(j0 + lg.Ls, g.nj);
+        const bool act = lane >= 1 && lane <= nu;
+        // mirrored lane order of the substitution
+        const int lane_m = 63 - lane;
+        const int col_m = wrap_index(strip * lg.wstrip - 1 + lane_m, g.ni, op.per_i);
+        const size_t colo_m = (size_t)(col_m >= 0 ? col_m : 0) + CO;
+        const bool act_m = lane_m >= 1 && lane_m <= nu;
+        const int j0 = seg * lg.Ls_i, j1 = min(j0 + lg.Ls_i, g.nj);
         auto xrow = [&](int j) -> double {
             if (ZERO) return 0.0;
             const int mr = mem_row(j, g, op.per_j);
             return (cvalid && mr >= 0) ? xin[(size_t)mr * P + colo] : 0.0;
         };
         double xs = xrow(j0 - 1), xc = xrow(j0);
+#pragma unroll 2
         for (int j = j0; j < j1; ++j) {
-            const size_t c = (size_t)(j + NG) * P + colo;
+            const size_t c = (size_t)(j + NG) * P + colo, cm = (size_t)(j + NG) * P + colo_m;
             const double xn = xrow(j + 1);
-            // equation of the lane: a x_{l-1} + d x_l + cc x_{l+1} = r; halo / outside lanes hold their old value
-            double a = 0.0, cc = 0.0, d = 1.0, r = ZERO ? 0.0 : (cvalid ? xc : 0.0);
+            double m = 0.0, r = 0.0;
             if (act) {
-                a = -op.ci[c]; cc = -op.ci[c + 1]; d = op.D[c];
-                r = b[c] + op.cj[c] * xs + op.cj[c + P] * xn;
+                m = lm[c];
+                r = b[c];
+                if (!ZERO) r += cj[c] * xs + cj[c + P] * xn;
             }
-            double id = fast_rcp(d);
-#pragma unroll
-            for (int s2 = 1; s2 < 64; s2 <<= 1) {
-                const int lm_ = lane - s2, lp_ = lane + s2;
-                const bool hm = lm_ >= 0, hp = lp_ < 64;
-                const int sm_ = hm ? lm_ : lane, sp_ = hp ? lp_ : lane;
-                double am = shfl_from(a, sm_), cm = shfl_from(cc, sm_), rm = shfl_from(r, sm_), im = shfl_from(id, sm_);
-                double ap = shfl_from(a, sp_), cp = shfl_from(cc, sp_), rp = shfl_from(r, sp_), ip = shfl_from(id, sp_);
-                if (!hm) { am = 0.0; cm = 0.0; rm = 0.0; im = 1.0; }
-                if (!hp) { ap = 0.0; cp = 0.0; rp = 0.0; ip = 1.0; }
-                const double k1 = a * im, k2 = cc * ip;
-                d = d - cm * k1 - ap * k2;
-                r = r - rm * k1 - rp * k2;
-                a = -am * k1;
-                cc = -cp * k2;
-                id = fast_rcp(d);
+            if (!ZERO) {        // old values of the two cells next to the block ends (explicit couplings)
+                const double xl = lane_left(xc), xr = lane_right(xc);
+                if (lane == 1) r += ci[c] * xl;
+                if (lane == nu) r += ci[c + 1] * xr;
             }
-            const double xt = r * id;
-            if (act) {
-                const double xo = ZERO ? 0.0 : xc;
-                xout[c] = xo + omega * (xt - xo);
+            const double gl = wave_recurrence(m, r);
+            const double gm = shfl_from(gl, lane_m);
+            double e = 0.0, h = 0.0, xo = 0.0;
+            if (act_m) {
+                const double iv = linv[cm];
+                h = gm * iv;
+                if (lane_m < nu) e = ci[cm + 1] * iv;
+                if (!ZERO) xo = xin[cm];
             }
+            const double xt = wave_recurrence(e, h);
+            if (act_m) xout[cm] = xo + omega * (xt - xo);
             xs = xc; xc = xn;
         }
     }
@@ -2369,8 +2457,16 @@ int build_pressure_hierarchy(Ctx *c) {
             CFD_TRY(read_scalars(c, 72, 2, a));
             L.aniso = fmax(-a[0], -a[1]);
             const bool big_enough = L.g.ni >= 4 && L.g.nj >= 4;
-            L.line = big_enough && (c->mg_line > 0 || (c->mg_line < 0 && L.aniso > c->mg_line_threshold));
-            if (L.line) need += 2 * L.g.plane_elems() * sizeof(double);
+            // directions: mg_line_dirs = 3: both wherever a level is line-smoothed; 0: each direction by its own ratio
+            // (a wall-graded channel is strongly coupled along j everywhere and never along i)
+            L.line_dirs = 0;
+            if (big_enough && c->mg_line > 0) L.line_dirs = 3;
+            else if (big_enough && c->mg_line < 0 && L.aniso > c->mg_line_threshold) {
+                L.line_dirs = c->mg_line_dirs ? 3 : ((-a[0] > c->mg_line_threshold ? 1 : 0) | (-a[1] > c->mg_line_threshold ? 2 : 0));
+            }
+            L.line = L.line_dirs != 0;
+            if (L.line_dirs & 1) need += 2 * L.g.plane_elems() * sizeof(double);
+            if (L.line_dirs & 2) need += 2 * L.g.plane_elems() * sizeof(double);
         }
         if (need > c->line_mem_bytes) {
             if (c->line_mem) CFD_HIP(hipFree(c->line_mem));
@@ -2386,13 +2482,23 @@ int build_pressure_hierarchy(Ctx *c) {
             if (!L.line) continue;
             ++n_line;
             const size_t pb = L.g.plane_elems() * sizeof(double);
-            L.lm = (double *)(c->line_mem + off);
-            L.linv = (double *)(c->line_mem + off + pb);
-            off += 2 * pb;
             const LineGeo lg = line_geo(L.g);
-            const long n = (long)L.g.ni * lg.nsegs;
-            const int nb = (int)std::min<long>((n + 255) / 256, 2048);
-            hipLaunchKernelGGL(k_line_factor_j, dim3(nb), dim3(256), 0, st, level_op(c, L), lg, L.lm, L.linv);
+            if (L.line_dirs & 1) {
+                L.lm = (double *)(c->line_mem + off);
+                L.linv = (double *)(c->line_mem + off + pb);
+                off += 2 * pb;
+                const long n = (long)L.g.ni * lg.nsegs;
+                const int nb = (int)std::min<long>((n + 255) / 256, 2048);
+                hipLaunchKernelGGL(k_line_factor_j, dim3(nb), dim3(256), 0, st, level_op(c, L), lg, L.lm, L.linv);
+            }
+            if (L.line_dirs & 2) {
+                L.lmi = (double *)(c->line_mem + off);
+                L.linvi = (double *)(c->line_mem + off + pb);
+                off += 2 * pb;
+                const long n = (long)L.g.nj * lg.nstrips;
+                const int nb = (int)std::min<long>((n + 255) / 256, 2048);
+                hipLaunchKernelGGL(k_line_factor_i, dim3(nb), dim3(256), 0, st, level_op(c, L), lg, L.lmi, L.linvi);
+            }
             CFD_HIP(hipGetLastError());
         }
         if (n_line > c->kc[KC_MG_LINE_LEVELS_MAX]) c->kc[KC_MG_LINE_LEVELS_MAX] = n_line;
@@ -2439,18 +2545,20 @@ static int line_smooth(Ctx *c, const Level &L, const OpDev &op, const double *rh
                        bool zero_guess, bool distributed) {
     hipStream_t st = c->stream;
     const LineGeo lg = line_geo(L.g);
-    const dim3 grid(line_blocks(lg)), gridj(line_blocks(lg, LJ_WAVES));
+    const dim3 grid(line_blocks(lg)), gridi(line_blocks(lg, true));
     const Tiling T = tiling(L.g);
     const double om = c->mg_line_omega;
     bool zero = zero_guess;
     auto sweep = [&](int kind) -> int {         // 0: j-lines, 1: i-lines, 2: point
+        if (kind == 0 && !(L.line_dirs & 1)) return CFD_OK;
+        if (kind == 1 && !(L.line_dirs & 2)) return CFD_OK;
         if (!zero && distributed) CFD_TRY(halo_exchange(c, L.g, 1, *cur));
         if (kind == 0) {
-            if (zero) hipLaunchKernelGGL((k_line_j<true>), gridj, dim3(64 * LJ_WAVES), 0, st, op, lg, L.lm, L.linv, rhs, (const double *)nullptr, om, *oth);
-            else hipLaunchKernelGGL((k_line_j<false>), gridj, dim3(64 * LJ_WAVES), 0, st, op, lg, L.lm, L.linv, rhs, (const double *)*cur, om, *oth);
+            if (zero) hipLaunchKernelGGL((k_line_j<true>), grid, dim3(256), 0, st, op, lg, L.lm, L.linv, rhs, (const double *)nullptr, om, *oth);
+            else hipLaunchKernelGGL((k_line_j<false>), grid, dim3(256), 0, st, op, lg, L.lm, L.linv, rhs, (const double *)*cur, om, *oth);
         } else if (kind == 1) {
-            if (zero) hipLaunchKernelGGL((k_line_i<true>), grid, dim3(256), 0, st, op, lg, rhs, (const double *)nullptr, om, *oth);
-            else hipLaunchKernelGGL((k_line_i<false>), grid, dim3(256), 0, st, op, lg, rhs, (const double *)*cur, om, *oth);
+            if (zero) hipLaunchKernelGGL((k_line_i<true>), gridi, dim3(256), 0, st, op, lg, L.lmi, L.linvi, rhs, (const double *)nullptr, om, *oth);
+            else hipLaunchKernelGGL((k_line_i<false>), gridi, dim3(256), 0, st, op, lg, L.lmi, L.linvi, rhs, (const double *)*cur, om, *oth);
         } else {
             if (zero) hipLaunchKernelGGL(k_mg_first, dim3(T.blocks), block2d(), 0, st, L.g, T, L.D, rhs, om, *oth);
             else hipLaunchKernelGGL(k_mg_jacobi, dim3(T.blocks), block2d(), 0, st, op, T, rhs, (const double *)*cur, om, *oth);
