@@ -1075,7 +1075,7 @@ struct ResidFuse {
     double *rnew;
 };
 
-template <bool UP, bool RF = false>
+template <bool UP, bool RF = false, bool XO = false>
 __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, const Geo &g, const Geo &gc, const double *b,
                                          const double *x, const double *e, int j, bool cvalid, size_t colo, size_t coloc,
                                          MgRaw &R, const double *q = nullptr) {
@@ -1088,6 +1088,7 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
         R.x = x[cc];
         R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
+    if (XO) R.x = x[cc];
     R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
     if (RF) R.q = q[cc];
     R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
@@ -1238,6 +1239,66 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
         if (lane == 0) sm[wave] = w;
         __syncthreads();
         if (threadIdx.x == 0) partials[blockIdx.x] = sum_waves<WPB>(sm);
+    }
+}
+
+// Tail of a line-smoothed pre-smoothing pass in one marching pass: one damped point-Jacobi sweep on the iterate the
+// line sweeps left, the residual of the result and its restriction (k_mg_jacobi + k_mg_restrict: 48 + 42 B per cell
+// and 2 launches).  Two halo lanes / rows per side: the residual of a cell needs its neighbours after the sweep.
+template <int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void k_mg_down_x(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *xin, double omega,
+                                                        double *xout, Geo gc, double *bc) {
+    const Geo g = op.g;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t P = g.pitch;
+    constexpr int K = 2, W = 64 - 2 * K;
+    const MarchItems<WPB> items(mg.nstrips, mg.nsegs, mg.xcd, wave);
+    for (int item = items.first; item < items.count; item += items.stride) {
+        int strip, seg;
+        bool active;
+        items.decode(item, mg.nstrips, wave, strip, seg, active);
+        const int iraw = strip * W - K + lane;
+        const int col = wrap_index(iraw, g.ni, op.per_i);
+        const bool cvalid = col >= 0;
+        const size_t colo = (size_t)(cvalid ? col : 0) + CO;
+        const bool out = lane >= K && lane < 64 - K && iraw < g.ni && active;
+        const int j0 = seg * mg.Ls, j1 = min(j0 + mg.Ls, g.nj);
+        // RC[s], V[s]: row j - s;  X0: the incoming iterate on rows (j - 2, j - 1, j);  X1: after the sweep on rows (j - 3, j - 2, j - 1)
+        RowC RC[3];
+        bool V[3];
+        double X0[3] = {0.0, 0.0, 0.0}, X1[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2) { RC[s2] = RowC{0.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0}; V[s2] = false; }
+        double rsum = 0.0;
+        MgRaw nxt;
+        mg_fetch<false, false, true>(op, df, g, gc, b, xin, nullptr, j0 - K, cvalid, colo, 0, nxt);
+        for (int j = j0 - K; j < j1 + K; ++j) {
+            const MgRaw cur = nxt;
+            if (j + 1 < j1 + K) mg_fetch<false, false, true>(op, df, g, gc, b, xin, nullptr, j + 1, cvalid, colo, 0, nxt);
+            RC[0] = mg_row(cur, df, op, colo);
+            V[0] = cur.valid;
+            X0[2] = cur.valid ? cur.x : 0.0;
+            double v = jac(X0[1], X0[0], X0[2], RC[1], omega);              // the sweep on row j - 1
+            if (!V[1]) v = 0.0;
+            X1[2] = v;
+            const int row = j - 1;
+            if (row >= j0 && row < j1 && out) xout[(size_t)(row + NG) * P + colo] = v;
+            // residual on row j - 2, summed over 2 x 2 aggregates into the coarse right-hand side
+            const int jo = j - 2;
+            const double res = resid(X1[1], X1[0], X1[2], RC[2]);
+            if (jo >= j0 && jo < j1) {
+                rsum += res;
+                if (((jo - j0) & 1) || jo == j1 - 1) {
+                    const double tot = rsum + lane_right(rsum);
+                    if (out && !((lane - K) & 1)) bc[gc.cell(iraw >> 1, jo >> 1)] = (iraw + 1 < g.ni) ? tot : rsum;
+                    rsum = 0.0;
+                }
+            }
+            RC[2] = RC[1]; RC[1] = RC[0]; V[2] = V[1]; V[1] = V[0];
+            X0[0] = X0[1]; X0[1] = X0[2];
+            X1[0] = X1[1]; X1[1] = X1[2];
+            if (WPB > 4) __syncthreads();
+        }
     }
 }
 
@@ -2542,7 +2603,7 @@ int build_pressure_hierarchy(Ctx *c) {
 // One pass of the alternating line smoother on level L: x_in (nullptr: zero) -> result; the planes ping-pong
 // between cur and oth, the result ends in *cur.  pre: j-lines, i-lines, point; post: point, i-lines, j-lines.
 static int line_smooth(Ctx *c, const Level &L, const OpDev &op, const double *rhs, double **cur, double **oth, bool post,
-                       bool zero_guess, bool distributed) {
+                       bool zero_guess, bool distributed, bool skip_point = false) {
     hipStream_t st = c->stream;
     const LineGeo lg = line_geo(L.g);
     const dim3 grid(line_blocks(lg)), gridi(line_blocks(lg, true));
@@ -2550,6 +2611,7 @@ static int line_smooth(Ctx *c, const Level &L, const OpDev &op, const double *rh
     const double om = c->mg_line_omega;
     bool zero = zero_guess;
     auto sweep = [&](int kind) -> int {         // 0: j-lines, 1: i-lines, 2: point
+        if (kind == 2 && skip_point) return CFD_OK;      // the caller's fused transfer kernel does the point sweep
         if (kind == 0 && !(L.line_dirs & 1)) return CFD_OK;
         if (kind == 1 && !(L.line_dirs & 2)) return CFD_OK;
         if (!zero && distributed) CFD_TRY(halo_exchange(c, L.g, 1, *cur));
@@ -2579,6 +2641,17 @@ static int line_smooth(Ctx *c, const Level &L, const OpDev &op, const double *rh
         if ((wide) == 8) hipLaunchKernelGGL(K8, grid, dim3(512), 0, st, __VA_ARGS__);   \
         else hipLaunchKernelGGL(K4, grid, dim3(256), 0, st, __VA_ARGS__);               \
     } while (0)
+
+// line-smoothed level whose point sweep is fused with the grid transfers (k_mg_down_x, k_mg_up_k<false, 1>)
+static inline bool line_transfer_fusable(const Ctx *c, int lvl, const Geo &F, const Geo &C) {
+    return c->mg_fused && c->levels[lvl].line && lvl >= c->l_agg && !F.cutlo && !F.cuthi && F.ni >= 16 && F.nj >= 16 &&
+           C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
+}
+static inline MarchGeo march_geo_w(const Geo &g, int W) {
+    MarchGeo m = march_geo(g);
+    m.nstrips = (g.ni + W - 1) / W;
+    return m;
+}
 
 // One V-cycle: z ~= A^-1 r starting from zero.  The result lands in *zout, which is
 // either z0 or z1 (Jacobi ping-pong).
@@ -2660,6 +2733,15 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         } else if (L.line) {
             // alternating line smoother from a zero guess (its first sweep writes the other plane), then residual + restriction
             std::swap(cur[l], oth[l]);
+            if (line_transfer_fusable(c, l, L.g, cg)) {
+                CFD_TRY(line_smooth(c, L, op, rhs[l], &cur[l], &oth[l], false, true, false, true));
+                const MarchGeo mgeo = march_geo_w(L.g, 60);
+                hipLaunchKernelGGL((k_mg_down_x<4>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, DiagFix{}, rhs[l], (const double *)cur[l],
+                                   c->mg_line_omega, oth[l], cg, cb);
+                CFD_HIP(hipGetLastError());
+                std::swap(cur[l], oth[l]);
+                continue;
+            }
             CFD_TRY(line_smooth(c, L, op, rhs[l], &cur[l], &oth[l], false, true, l < la));
             CFD_TRY(halo_exchange(c, L.g, 1, cur[l]));
             int fi, fj;
@@ -2756,6 +2838,15 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             }
             std::swap(cur[l], oth[l]);
             CFD_HIP(hipGetLastError());
+            continue;
+        }
+        if (line_transfer_fusable(c, l, L.g, cg)) {
+            const MarchGeo mgeo = march_geo_w(L.g, 62);
+            hipLaunchKernelGGL((k_mg_up_k<false, 1>), dim3(march_blocks(mgeo)), dim3(256), 0, st, op, mgeo, DiagFix{}, rhs[l], (const double *)cur[l],
+                               cg, e, c->mg_gamma, SweepOm<1>{{c->mg_line_omega}}, oth[l], c->partials, 0);
+            CFD_HIP(hipGetLastError());
+            std::swap(cur[l], oth[l]);
+            CFD_TRY(line_smooth(c, L, op, rhs[l], &cur[l], &oth[l], true, false, false, true));
             continue;
         }
         const Tiling T = tiling(L.g);
