@@ -92,7 +92,8 @@ def setup_annulus(nr, nt, max_iter, tol, device, tuning=None):
     return dev, ctl, cfg
 
 
-def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, tuning=None, lookahead=True, graded=False):
+def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, tuning=None, lookahead=True, graded=False,
+                 private=False):
     """One n x n slab per GPU of an n x (n * world) channel of height `world` (same cells, same cell
     size on every rank: weak scaling); world = 1 is the single-GPU workload of SURVEY.md 8(d).
     --strong calls this with world = 1 under an initialised process group: the n x n channel itself is
@@ -114,7 +115,12 @@ def setup_device(n, turbulent, max_iter, tol, device, world=1, transport=None, t
     if not lookahead:
         cfg["solver"]["flux_kernels"] = {"marching": True, "lookahead": False}
     x, y = rect_node_axes(**mp)
-    dev = slab_device(n, n * world, device, transport=transport)
+    if private:         # a context of this rank alone, whatever process group exists (the settle phase of main())
+        from cfd_amd.device import Device
+        dev = Device(n, n * world, device)
+        dev.j_offset, dev.nj_global, dev.rank, dev.nranks = 0, n * world, 0, 1
+    else:
+        dev = slab_device(n, n * world, device, transport=transport)
     dev.mesh_from_rect(x, y)
     ctl = StepControl(cfg)
     configure_device(dev, cfg, BoundaryGeometry.from_rect_axes(x, y), cfg["physics"]["nu"], ctl.turb_on)
@@ -255,6 +261,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=170.0, help="seconds the CPU baseline may take in all; sizes "
                     "whose estimated cost would exceed it are skipped and say so")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--settle", type=float, default=6.0, help="seconds of untimed GPU work on a separate small context before "
+                    "the warm-up steps (the first GPU process on a freshly started machine stalls once for ~40 ms a "
+                    "few seconds after it initialised the GPU; see DESIGN.md 5)")
     ap.add_argument("--probe", type=int, default=-1, help="kernel id of the live roofline probe (-1: the candidate with the "
                     "largest share of device time; 0 = PCG direction step, 8 / 9 = momentum Chebyshev with two / one "
                     "right-hand sides, 7 / 1 / 10 = multigrid up / down / down with residual update, 2 = momentum RHS)")
@@ -326,6 +335,15 @@ def main():
         nu_s = args.mg_sweeps or 3
         dev.set_multigrid(nu_pre=nu_s, nu_post=nu_s,
                           omegas=[float(v) for v in args.mg_omegas.split(",")] if args.mg_omegas else None)
+    if args.settle > 0.0:
+        t_settle = time.perf_counter()
+        sdev, sctl, _ = setup_device(1024, args.turbulent, args.max_iter, args.tol, local, private=True)
+        sstep = 0
+        while time.perf_counter() - t_settle < args.settle:
+            advance_one_step(sdev, sctl, sstep)
+            sstep += 1
+        sdev.synchronize()
+        sdev.close()
     step = 0
     iters = []
     # ---- the event-pair probe runs on EVERY hot kernel inside the timed region (cfd_probe(CFD_PROBE_ALL): two event
@@ -342,11 +360,13 @@ def main():
     phase0 = dev.comm_counts_by_phase()
     barrier()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         info = advance_one_step(dev, ctl, step)
         st = dev.stats()
         iters.append((st["mom_iters"], st["p_iters"], st["k_iters"]))
         step += 1
+        step_marks.append(time.perf_counter())      # host clock, no synchronisation: the host is at most one read ahead
     dev.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -487,7 +507,9 @@ def main():
             "frac_of_hbm_peak": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
             "note": "includes the pressure right-hand side kernel and the host residual checks of the solve"}
         out["weak_scaling_leg" if strong else "strong_scaling_leg"] = other_leg
+        out["settle_s"] = args.settle     # untimed work on a separate 1024^2 context before the warm-up steps (--settle)
         out["phase_ms_per_step"] = {k: 1e3 * v / extra_steps for k, v in phases.items()}
+        out["step_ms_host_clock"] = [round(1e3 * (b_ - a_), 2) for a_, b_ in zip([t0] + step_marks[:-1], step_marks)]
         out["device_copy_GBps"] = copy_gbs
         if world == 1 and not args.no_cpu:
             sizes = [int(v) for v in args.cpu_size.split(",") if v]
