@@ -399,7 +399,11 @@ int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, doub
  * on the anisotropic / no / all levels; with "mg_line_threshold" and "mg_line_omega" it changes the V-cycle, hence
  * iteration counts, not the converged solution); "scalar_nu" (0 / 1: cfd_momentum_diagonal forms the face conductances
  * from the scalar nu alone, the scalar branch of solver._diffusion_coefficients, solver.py:205-207, for callers of the
- * per-phase functions that pass a scalar viscosity).  No counterpart in the reference.     */
+ * per-phase functions that pass a scalar viscosity); "mg_line_dirs" (1 / 0: both line directions on a line-smoothed level /
+ * only those whose own coupling ratio exceeds the threshold), "mg_tail" (1 / 0: V-cycle tail in one launch), "wide_mask"
+ * (bit mask of the marching kernels that run as lockstep workgroups), "host_lag" (1 / 0: lagged host reads of the
+ * residual norms), "plane_swap" (1 / 0: Chebyshev results adopted by pointer exchange / copied), "xcd_map", "mg_gamma",
+ * "mg_om0" .. "mg_om2" (smoother dampings).  INTEGRATION.md section 4 has the table.  No counterpart in the reference.     */
 int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
 /* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels
  * its run went through: [0] 4-iteration Chebyshev launches with two right-hand sides, [1] with one, [2] 2-iteration
