@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # 8192^2 (tools/pmc_summary.py: FETCH_SIZE x 2 + WRITE_SIZE, fabric side, Infinity-Cache hits included)
 PMC_TRAFFIC_BYTES_PER_CELL_8192 = {}       # filled from profiles/r2*_pmc8192_bytes_per_cell.csv when present
 PMC_KERNEL_OF_PROBE = {0: "k_cg_pq", 8: "k_chebk<2,4", 9: "k_chebk<1,4", 7: "k_mg_up_k<true", 1: "k_mg_down_k<true,3,false",
-                       10: "k_mg_down_k<true,3,true", 2: "k_flux_march<2"}
+                       10: "k_mg_down_k<true,3,true", 2: "k_correct_flux<"}
 
 
 def load_pmc_traffic():
@@ -194,8 +194,9 @@ def cpu_baseline(n_cpu, steps, max_iter):
 KERNEL_NAMES = {
     0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq)",
     1: "MG pre-smoother, finest level: 3 fused Jacobi sweeps + residual + restrict (k_mg_down_k<true,3>)",
-    2: "momentum RHS + continuity sum (+ next step's time-step minima in laminar runs, + grad(2/3 k) in k-omega runs), "
-       "marching Rhie-Chow flux kernel (k_flux_march<2>)",
+    2: "velocity / pressure correction + ghost cells + momentum RHS + continuity sum (+ next step's time-step minima in "
+       "laminar runs, + grad(2/3 k) in k-omega runs) in one marching pass (k_correct_flux, 176-184 B/cell; the first "
+       "iteration of a run and contexts the fused pass does not cover run the Rhie-Chow kernel k_flux_march<2>, 120-128 B/cell)",
     8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>)",
     9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
     10: "MG pre-smoother with the PCG residual update folded in (k_mg_down_k<true,3,true>)",

@@ -623,7 +623,9 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "mg_gamma") { if (!(value > 0.0 && value <= 2.0)) { set_error("mg_gamma: (0, 2]"); return CFD_E_ARG; } c->mg_gamma = value; }
     else if (n == "mg_om0" || n == "mg_om1" || n == "mg_om2") { if (!(value > 0.0 && value <= 1.5)) { set_error("mg_om*: (0, 1.5]"); return CFD_E_ARG; } c->mg_om[n[5] - '0'] = value; }
     else if (n == "xcd_map") c->xcd_map = iv ? 1 : 0;
-    else if (n == "wide_mask") { if (iv < 0 || iv > 511) { set_error("wide_mask: 0 .. 511"); return CFD_E_ARG; } c->wide_mask = iv; }
+    else if (n == "fuse_correct") c->fuse_correct = iv ? 1 : 0;
+    else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
+    else if (n == "wide_mask") { if (iv < 0 || iv > 1023) { set_error("wide_mask: 0 .. 1023"); return CFD_E_ARG; } c->wide_mask = iv; }
     else if (n == "mg_tail") { c->mg_tail = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
     else if (n == "mg_line_dirs") { c->mg_line_dirs = iv ? 1 : 0; c->p_built = false; }
@@ -708,6 +710,13 @@ int cfd_set_flow_bc(cfd_ctx *ctx, int side, int n, const int32_t *kind_uv, const
     CFD_HIP(hipStreamSynchronize(c->stream));
     S.n = n;
     c->fbc_set[side] = true;
+    // what the fused correction / flux pass asks of a side (correct_flux_ok)
+    bool all_per = true, all_local = true;
+    for (int t = 0; t < n; ++t) {
+        if (!(kind_uv[t] == CFD_BC_PERIODIC && kind_p[t] == CFD_BC_PERIODIC)) all_per = false;
+        if (!((kind_uv[t] == CFD_BC_AFFINE || kind_uv[t] == CFD_BC_SYMMETRY) && kind_p[t] == CFD_BC_AFFINE)) all_local = false;
+    }
+    c->fbc_class[side] = all_per ? 1 : (all_local ? 2 : 0);
     return CFD_OK;
 }
 
@@ -931,6 +940,27 @@ int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, dou
     CFD_TRY(do_predictor(c, dt, res));
     CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P()));
     CFD_TRY(do_pressure(c, c->U1(), c->V1(), c->P()));
+    if (correct_flux_ok(c)) {
+        // correction, ghost cells and the closing flux pass (continuity sum, next right-hand sides, time-step minima) in
+        // one marching kernel; the memory ghosts of the corrected fields are filled afterwards
+        bool dt_too = false;
+        int nb = 0;
+        {
+            Phase ph(c, PH_CORR);
+            CFD_TRY(launch_pcorr_bc(c));
+            c->probe_begin(2);
+            CFD_TRY(launch_correct_flux(c, dt, relax_u, relax_v, relax_p, &dt_too, &nb));
+            c->probe_end(2, c->last_rhs_bytes);
+            c->cur ^= 1;
+        }
+        CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
+        Phase ph(c, PH_CONT);
+        CFD_TRY(finish_correct_flux(c, dt_too, nb, &res[0]));
+        c->rhs_ahead = true;
+        c->rhs_dt = dt;
+        c->rhs_cur = c->cur;
+        return CFD_OK;
+    }
     {
         Phase ph(c, PH_CORR);
         CFD_TRY(launch_pcorr_bc(c));

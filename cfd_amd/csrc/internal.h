@@ -181,7 +181,7 @@ __device__ __forceinline__ void store_stream(double *p, double v, int nt) {
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
-    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_COUNT = 16
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_COUNT = 16
 };
 
 // ------------------------------------------------------------------ multigrid level
@@ -294,6 +294,9 @@ struct Ctx {
     char *bc_buf = nullptr;      // device buffer for flow tables
     FlowBCDev fbc{};
     bool fbc_set[4] = {false, false, false, false};
+    int fbc_class[4] = {0, 0, 0, 0};   // 1: every entry periodic (u, v and p); 2: every entry AFFINE / SYMMETRY (u, v) and AFFINE (p); 0: anything else
+    int cf_form = 2;                   // k_correct_flux on meshes of >= 16 strips: 0 independent waves, 1 lockstep workgroups of 8 strips, 2 of 4
+    int fuse_correct = 1;              // correction + boundary fill + closing flux pass in one marching kernel where correct_flux_ok()
     int per_i = 0, per_j = 0, wrap_p_i = 0, wrap_p_j = 0;
     int32_t *pmask[4] = {nullptr, nullptr, nullptr, nullptr};
     int pp_per_i = 0, pp_per_j = 0, has_dirichlet = 0, pin_i = 0, pin_j = 0;
@@ -506,6 +509,9 @@ int time_kernel(Ctx *c, int kernel, int reps, double *avg_us);
 // stencil.hip: entry points of the per-phase host wrappers
 int launch_momentum_rhs_given(Ctx *c, double dt, const double *advu, const double *advv, const double *extra, double force_u,
                               double force_v);
+bool correct_flux_ok(const Ctx *c);
+int launch_correct_flux(Ctx *c, double dt, double ru, double rv, double rp, bool *dt_too, int *nb);
+int finish_correct_flux(Ctx *c, bool dt_too, int nb, double *cont);
 int launch_wall_friction(Ctx *c, int side, int lo, int n, const double *tab_dev, double nu, double rho, int use_nut,
                          double *tau_dev, double out[2]);
 

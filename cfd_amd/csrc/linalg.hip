@@ -2079,8 +2079,13 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         ChebStages<K> cf;
         for (int s2 = 0; s2 < K; ++s2) cc.next(cf.c1[s2], cf.c2[s2]);
         const int probe_id = (na == 2) ? 8 : 9;      // 8: both right-hand sides in the launch, 9: one
-        const int wide = na == 2 ? wide2 : wide1;
-        const bool lock4 = wide == 4 && na == 2 && NB == 2 && wide_ok && (c->wide_mask & 256) && mgeo.nstrips >= 16;
+        const int wide_in = na == 2 ? wide2 : wide1;
+        // lockstep workgroups of four strips: the two-right-hand-side form (two waves per SIMD) and, bit 512, the
+        // one-right-hand-side form (154 registers = three waves per SIMD: one workgroup of eight leaves a third of the
+        // CU's wave slots empty, three workgroups of four fill them)
+        const bool lock4 = wide_ok && mgeo.nstrips >= 16 &&
+                           ((wide_in == 4 && na == 2 && NB == 2 && (c->wide_mask & 256)) || (na == 1 && (c->wide_mask & 512) && (c->wide_mask & WIDE_CHEB1)));
+        const int wide = lock4 ? 4 : wide_in;
         const dim3 grid(march_grid(mgeo, wide, lock4));
         c->probe_begin(probe_id);
         if (na == NB) {
@@ -2114,6 +2119,8 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                                    xm, o1, o2, c->partials);
             else if (wide == 8)
                 hipLaunchKernelGGL((k_chebk<1, K, 2, 8>), grid, dim3(512), 0, st, op, mgeo, cf, 0, c->nts(), b1, xk, xm, o1, o2, c->partials);
+            else if (lock4)
+                hipLaunchKernelGGL((k_chebk<1, K, 2, 4, true>), grid, dim3(256), 0, st, op, mgeo, cf, 0, c->nts(), b1, xk, xm, o1, o2, c->partials);
             else if (c->cheb_prefetch == 2)
                 hipLaunchKernelGGL((k_chebk<1, K, 2>), grid, dim3(256), 0, st, op, mgeo, cf, 0, c->nts(), b1, xk, xm, o1, o2, c->partials);
             else

@@ -819,6 +819,326 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
     }
 }
 
+// ----------------------------------------------------------------------------------
+// Correction + boundary fill + closing flux pass of a SIMPLE iteration in ONE marching pass: k_correct (136 B/cell)
+// and k_flux_march<2, ., DT> (128 B/cell) share the metric planes, V and a_P and hand u, v, p to each other through
+// HBM; here a wave corrects a row as it enters its window (u = u0 + ru ((u* - V/a_P grad p') - u0), ..., the
+// expressions of k_correct / green_gauss), fills the ghost cells it needs from the BC tables in registers (the
+// expressions of k_flow_bc: rows -1 and nj from the corrected rows 0 and nj - 1, ghost columns from the neighbouring
+// lane; a periodic i-direction needs nothing, the halo lanes correct the wrapped cells themselves), stores the
+// corrected interior and runs the MODE 2 body of k_flux_march on the registers: 17 planes read, 5 written = 176 B/cell
+// instead of 264.  Two halo lanes / rows per side (the gradient of p' needs one more than the fluxes).  The memory
+// ghosts of u, v, p are filled by k_flow_bc afterwards, as before.  u*, v* are read by neighbouring waves, so the
+// corrected u, v go to two other planes (the caller rebinds the plane pointers).
+// Conditions (launch_correct_flux checks them): one rank, no periodicity along j, every entry of the j-side tables
+// AFFINE / SYMMETRY (u, v) and AFFINE (p), the i-sides either periodic (with the p wrap) or like the j-sides.
+// ----------------------------------------------------------------------------------
+constexpr int CFW = 60;
+struct CorrIn {
+    const double *us, *vs, *u0, *v0, *p0, *pc, *ap;
+    double *uo, *vo, *po;
+    double ru, rv, rp;
+    int rc, per_i, nts;
+};
+// a raw row in two parts: the correction of row r needs E of the rows r, r + 1 but L of row r only, so E is
+// requested one row earlier than L and fewer registers wait for memory
+struct CorrE {
+    double pc, wnj, njx, njy;
+};
+struct CorrL {
+    double us, vs, u0, v0, p0, ap, vol;
+    double wri, nix, niy, si, sj;      // west / south face of the cell (lane ihi: west face = face ni)
+    double k, lmin;
+};
+__device__ __forceinline__ void bc_ghost(const FlowBCSide &s, int t, double ui, double vi, double pi, double &u, double &v, double &p) {
+    const int kuv = s.kind_uv[t];
+    if (kuv == CFD_BC_AFFINE) {
+        u = s.ua[t] * ui + s.ub[t];
+        v = s.va[t] * vi + s.vb[t];
+    } else {        // CFD_BC_SYMMETRY
+        const double nx = s.nx[t], ny = s.ny[t];
+        const double un = ui * nx + vi * ny;
+        u = ui - 2.0 * un * nx;
+        v = vi - 2.0 * un * ny;
+    }
+    p = s.pa[t] * pi + s.pb[t];
+}
+
+template <bool KG, bool DT, int WPB, bool LOCK = (WPB > 4)>
+__global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, CorrIn ci, FlowBCDev bc, FluxMarch fm, MomArgs ma,
+                                                           double *partials) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t P = g.pitch;
+    const int rc = ci.rc;
+    double acc = 0.0, acc2 = INFINITY, acc3 = INFINITY;
+    const MarchItems<WPB, LOCK> items(fm.nstrips, fm.nsegs, 0, wave);
+    for (int item = items.first; item < items.count; item += items.stride) {
+        int strip, seg;
+        bool active;
+        items.decode(item, fm.nstrips, wave, strip, seg, active);
+        const int iraw = strip * CFW - 2 + lane;          // -2 .. ni + 1
+        // cell whose fields this lane corrects: the wrapped cell (periodic i) or the nearest interior cell (the value
+        // of a ghost lane is then replaced from the BC tables)
+        int cw = iraw;
+        if (ci.per_i) { if (cw < 0) cw += g.ni; if (cw >= g.ni) cw -= g.ni; }
+        else cw = cw < 0 ? 0 : (cw >= g.ni ? g.ni - 1 : cw);
+        if (cw < 0) cw = 0;
+        if (cw >= g.ni) cw = g.ni - 1;
+        const size_t colw = (size_t)cw + CO;
+        // p' keeps its own ghost columns (k_pcorr_bc): a non-periodic boundary cell reads the ghost value
+        const int cp = ci.per_i ? cw : (iraw < -1 ? -1 : (iraw > g.ni ? g.ni : iraw));
+        const size_t colp = (size_t)(cp + CO);
+        const bool out = lane >= 2 && lane < 62 && iraw < g.ni && active;
+        const bool ilo = iraw == 0, ihi = iraw == g.ni;
+        const bool glo = !ci.per_i && iraw == -1, ghi = !ci.per_i && iraw == g.ni;      // ghost lanes of a non-periodic i-direction
+        const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
+        auto fetchE = [&](int r, CorrE &R) {
+            const int rr = r < -1 ? -1 : (r > g.nj ? g.nj : r);
+            const size_t c = (size_t)(rr + NG) * P + colw;
+            R.pc = ci.pc[(size_t)(rr + NG) * P + colp];
+            R.wnj = m.wnj[c]; R.njx = m.njx[c]; R.njy = m.njy[c];
+        };
+        auto kload = [&](int rr) -> double {
+            return KG ? (2.0 / 3.0) * ma.kgrad[(size_t)(rr + NG) * P + (size_t)((iraw < g.ni ? (iraw < -1 ? -1 : iraw) : g.ni) + CO)] : 0.0;
+        };
+        auto fetchL = [&](int r, CorrL &R) {
+            const int rr = r < -1 ? -1 : (r > g.nj ? g.nj : r);
+            const size_t c = (size_t)(rr + NG) * P + colw;
+            R.us = ci.us[c]; R.vs = ci.vs[c]; R.u0 = ci.u0[c]; R.v0 = ci.v0[c]; R.p0 = ci.p0[c];
+            R.ap = ci.ap[c]; R.vol = m.vol[c];
+            R.wri = m.wri[c]; R.nix = m.nix[c]; R.niy = m.niy[c]; R.si = m.si[c]; R.sj = m.sj[c];
+            R.k = kload(rr);
+            R.lmin = (DT && ma.use_diff) ? m.lmin[c] : 1.0;
+            if (ihi) {       // the west face of this lane is face ni, whose entries are separate from face 0's
+                const size_t ce = (size_t)(rr + NG) * P + (size_t)(g.ni + CO);
+                R.wri = m.wri[ce]; R.nix = m.nix[ce]; R.niy = m.niy[ce]; R.si = m.si[ce];
+            }
+        };
+        // raw window around row r: pcA = p' of row r - 1; Eb, Ec, Ed = E of rows r, r + 1, r + 2 (Ed in flight);
+        // Lb, Lc = L of rows r, r + 1 (Lc in flight)
+        double pcA;
+        CorrE Eb, Ec, Ed;
+        CorrL Lb, Lc;
+        auto correct_row = [&](int r, FluxRow &R) {       // r in [0, nj), in the form the flux stage reads
+            const double pcc = Eb.pc;
+            const double pW = lane_left(pcc), pE = lane_right(pcc);
+            // east face of the cell = west face of the right lane (lane ihi holds face ni, the east face of cell ni - 1)
+            const double wriE = lane_right(Lb.wri), nixE = lane_right(Lb.nix), niyE = lane_right(Lb.niy);
+            // lane ihi itself is a ghost (non-periodic, value replaced below) or the wrapped cell 0, whose own west face
+            // is face 0
+            double wri = Lb.wri, nix = Lb.nix, niy = Lb.niy;
+            if (ihi && ci.per_i) {
+                const size_t c0 = (size_t)(r + NG) * P + colw;
+                wri = m.wri[c0]; nix = m.nix[c0]; niy = m.niy[c0];
+            }
+            const double pw = (1.0 - wri) * pW + wri * pcc;
+            const double pe = (1.0 - wriE) * pcc + wriE * pE;
+            const double ps = (1.0 - Eb.wnj) * pcA + Eb.wnj * pcc;
+            const double pn = (1.0 - Ec.wnj) * pcc + Ec.wnj * Ec.pc;
+            const double vol = Lb.vol;
+            const double gx = (nixE * pe - nix * pw + Ec.njx * pn - Eb.njx * ps) / vol;
+            const double gy = (niyE * pe - niy * pw + Ec.njy * pn - Eb.njy * ps) / vol;
+            const double d = vol / Lb.ap;
+            const double uc = Lb.us - d * gx, vc = Lb.vs - d * gy;
+            double un = Lb.u0 + ci.ru * (uc - Lb.u0);
+            double vn = Lb.v0 + ci.rv * (vc - Lb.v0);
+            double pn2 = Lb.p0 + ci.rp * pcc;
+            if (out && r >= j0 && r < j1) {
+                const size_t c = (size_t)(r + NG) * P + colw;
+                store_stream(ci.uo + c, un, ci.nts);
+                store_stream(ci.vo + c, vn, ci.nts);
+                store_stream(ci.po + c, pn2, ci.nts);
+            }
+            // ghost columns of a non-periodic i-direction from the neighbouring interior lane (k_flow_bc)
+            const double uR = lane_right(un), vR = lane_right(vn), pR = lane_right(pn2);
+            const double uL = lane_left(un), vL = lane_left(vn), pL = lane_left(pn2);
+            if (glo) bc_ghost(bc.side[CFD_SIDE_IMIN], r, uR, vR, pR, un, vn, pn2);
+            if (ghi) bc_ghost(bc.side[CFD_SIDE_IMAX], r, uL, vL, pL, un, vn, pn2);
+            R.u = un; R.v = vn; R.p = pn2; R.ap = rc ? Lb.ap : 1.0;
+            R.wri = Lb.wri; R.nix = Lb.nix; R.niy = Lb.niy; R.si = Lb.si;
+            R.wnj = Eb.wnj; R.njx = Eb.njx; R.njy = Eb.njy; R.sj = Lb.sj;
+            R.vol = Lb.vol; R.k = Lb.k; R.lmin = Lb.lmin;
+        };
+        // first interior row this segment needs corrected
+        const int r0 = j0 > 0 ? j0 - 1 : 0;
+        FluxRow cur{}, prv{};
+        {
+            CorrE A;
+            fetchE(r0 - 1, A);
+            pcA = A.pc;
+            fetchE(r0, Eb);
+            fetchE(r0 + 1, Ec);
+            fetchE(r0 + 2, Ed);
+            fetchL(r0, Lb);
+            fetchL(r0 + 1, Lc);
+        }
+        int wrow = r0;                        // the row Eb / Lb hold
+        bool have_cur = false;
+        if (j0 == 0) {
+            // the ghost row -1 stands in prv: the flux stage reads only its u, v, p (and k), from the corrected row 0
+            correct_row(0, cur);
+            prv = cur;
+            prv.k = kload(-1);
+            bc_ghost(bc.side[CFD_SIDE_JMIN], cw, cur.u, cur.v, cur.p, prv.u, prv.v, prv.p);
+            have_cur = true;
+        }
+        double u2 = 0.0, v2 = 0.0, p2 = 0.0, k2 = 0.0;
+        double fw_p = 0.0, fs_p = 0.0, lw_p = 0.0, ls_p = 0.0;
+        for (int j = j0 > 0 ? j0 - 1 : 0; j <= j1; ++j) {
+            if (j < g.nj) {
+                if (!have_cur) {
+                    if (wrow != j) {          // window -> row j
+                        pcA = Eb.pc; Eb = Ec; Ec = Ed; Lb = Lc;
+                        fetchE(j + 2, Ed);
+                        fetchL(j + 1, Lc);
+                        wrow = j;
+                    }
+                    correct_row(j, cur);
+                }
+                have_cur = false;
+            } else {
+                // ghost row nj from the corrected row nj - 1 (= prv); its south-face entries and k are row nj's
+                bc_ghost(bc.side[CFD_SIDE_JMAX], cw, prv.u, prv.v, prv.p, cur.u, cur.v, cur.p);
+                cur.wnj = Ec.wnj; cur.njx = Ec.njx; cur.njy = Ec.njy; cur.sj = Lc.sj; cur.k = Lc.k;
+            }
+            // ---- from here on: the MODE 2 body of k_flux_march, same expressions
+            const double uL = lane_left(cur.u), vL = lane_left(cur.v), pL = lane_left(cur.p);
+            double fw_c, lw_c, ls_c;
+            {
+                const double wr = cur.wri, wl = 1.0 - wr;
+                const double ui = wl * uL + wr * cur.u;
+                const double vi = wl * vL + wr * cur.v;
+                fw_c = ui * cur.nix + vi * cur.niy;
+                lw_c = fw_c;
+                if (rc) {
+                    const double apL = lane_left(cur.ap);
+                    double af = ilo ? cur.ap : (ihi ? apL : wl * apL + wr * cur.ap);
+                    af = af > TINY ? af : TINY;
+                    const double s = cur.si;
+                    fw_c = fw_c - (s * s) / af * (cur.p - pL);
+                }
+            }
+            double fs_c;
+            {
+                const bool lo = g.blo(j), hi = (j == g.nj) && !g.cuthi;
+                const double wn = cur.wnj, ws = 1.0 - wn;
+                const double uj = ws * prv.u + wn * cur.u;
+                const double vj = ws * prv.v + wn * cur.v;
+                fs_c = uj * cur.njx + vj * cur.njy;
+                ls_c = fs_c;
+                if (rc) {
+                    double af = lo ? cur.ap : (hi ? prv.ap : ws * prv.ap + wn * cur.ap);
+                    af = af > TINY ? af : TINY;
+                    const double s = cur.sj;
+                    fs_c = fs_c - (s * s) / af * (cur.p - prv.p);
+                }
+            }
+            const int jo = j - 1;
+            const double fe_p = lane_right(fw_p);
+            const double le_p = DT ? lane_right(lw_p) : 0.0;
+            {
+                const double uW = lane_left(prv.u), uE = lane_right(prv.u);
+                const double vW = lane_left(prv.v), vE = lane_right(prv.v);
+                const double pW = lane_left(prv.p), pE = lane_right(prv.p);
+                const double wriE = lane_right(prv.wri), nixE = lane_right(prv.nix), niyE = lane_right(prv.niy);
+                const double kW = KG ? lane_left(prv.k) : 0.0, kE = KG ? lane_right(prv.k) : 0.0;
+                if (jo >= j0 && out) {
+                    const double fw = fw_p, fe = fe_p, fs = fs_p, fn = fs_c;
+                    const double vol = prv.vol;
+                    const size_t c = (size_t)(jo + NG) * P + colw;
+                    double advu, advv;
+                    {
+                        const double pc = prv.u;
+                        const double pw = fw >= 0.0 ? uW : pc, pe = fe >= 0.0 ? pc : uE;
+                        const double ps = fs >= 0.0 ? u2 : pc, pn = fn >= 0.0 ? pc : cur.u;
+                        const double div = fe * pe - fw * pw + fn * pn - fs * ps;
+                        advu = -div / vol;
+                    }
+                    {
+                        const double pc = prv.v;
+                        const double pw = fw >= 0.0 ? vW : pc, pe = fe >= 0.0 ? pc : vE;
+                        const double ps = fs >= 0.0 ? v2 : pc, pn = fn >= 0.0 ? pc : cur.v;
+                        const double div = fe * pe - fw * pw + fn * pn - fs * ps;
+                        advv = -div / vol;
+                    }
+                    double gx, gy;
+                    {
+                        const double pc = prv.p;
+                        const double pw = (1.0 - prv.wri) * pW + prv.wri * pc;
+                        const double pe = (1.0 - wriE) * pc + wriE * pE;
+                        const double ps = (1.0 - prv.wnj) * p2 + prv.wnj * pc;
+                        const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.p;
+                        gx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
+                        gy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                    }
+                    if (KG) {
+                        const double pc = prv.k;
+                        const double pw = (1.0 - prv.wri) * kW + prv.wri * pc;
+                        const double pe = (1.0 - wriE) * pc + wriE * kE;
+                        const double ps = (1.0 - prv.wnj) * k2 + prv.wnj * pc;
+                        const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.k;
+                        const double kx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
+                        const double ky = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        gx = gx + kx;
+                        gy = gy + ky;
+                    }
+                    const double su = advu - gx + ma.force_u, sv = advv - gy + ma.force_v;
+                    double b_u = vol * ma.inv_dt * prv.u + vol * su;
+                    double b_v = vol * ma.inv_dt * prv.v + vol * sv;
+                    if (!ma.per_i) {
+                        if (iraw == 0) { const double a = ma.ai[c]; b_u += a * uW; b_v += a * vW; }
+                        if (iraw == g.ni - 1) { const double a = ma.ai[c + 1]; b_u += a * uE; b_v += a * vE; }
+                    }
+                    if (!ma.per_j) {
+                        if (g.blo(jo)) { const double a = ma.aj[c]; b_u += a * u2; b_v += a * v2; }
+                        if (g.bhi(jo)) { const double a = ma.aj[c + P]; b_u += a * cur.u; b_v += a * cur.v; }
+                    }
+                    store_stream(ma.bu + c, b_u, ma.nts);
+                    store_stream(ma.bv + c, b_v, ma.nts);
+                    const double div = (fe - fw + fn - fs) / vol;
+                    acc += div * div;
+                    if (DT) {
+                        if (ma.use_cfl) {
+                            const double tot = fabs(lw_p) + fabs(le_p) + fabs(ls_p) + fabs(ls_c);
+                            const double safe = tot > TINY ? tot : TINY;
+                            acc2 = fmin(acc2, ma.cfl * vol / safe);
+                        }
+                        if (ma.use_diff) {
+                            const double ne = ma.nu + 0.0;
+                            const double ns = ne > 0.0 ? ne : TINY;
+                            const double l = prv.lmin;
+                            acc3 = fmin(acc3, ma.cfl_diff * (l * l) / ns);
+                        }
+                    }
+                }
+                u2 = prv.u; v2 = prv.v; p2 = prv.p; k2 = prv.k;
+            }
+            fw_p = fw_c; fs_p = fs_c;
+            lw_p = lw_c; ls_p = ls_c;
+            prv = cur;
+            if (LOCK) __syncthreads();
+        }
+    }
+    auto min_waves = [](const double *a) {
+        double r = a[0];
+#pragma unroll
+        for (int q = 1; q < WPB; ++q) r = fmin(r, a[q]);
+        return r;
+    };
+    __shared__ double sm[WPB], sa[WPB], sb[WPB];
+    const double w = wave_sum(acc);
+    const double wa = DT ? wave_min(acc2) : 0.0, wb = DT ? wave_min(acc3) : 0.0;
+    if (lane == 0) { sm[wave] = w; if (DT) { sa[wave] = wa; sb[wave] = wb; } }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = sum_waves<WPB>(sm);
+        if (DT) {
+            partials[MAX_PARTIALS + blockIdx.x] = min_waves(sa);
+            partials[2 * MAX_PARTIALS + blockIdx.x] = min_waves(sb);
+        }
+    }
+}
+
 constexpr int DT_AHEAD_OFF = 96;      // Ctx::scal slots of the time-step minima computed ahead
 
 int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff, double out[2]) {
@@ -895,6 +1215,81 @@ static int finish_continuity(Ctx *c, int nb, double *out, bool with_dt = false) 
     }
     *out = sqrt(s / global_cells(c));
     return CFD_OK;
+}
+
+// Host side of k_correct_flux: can this context take the fused pass, and the launch.
+bool correct_flux_ok(const Ctx *c) {
+    if (!c->fuse_correct || !c->march_flux || !c->rhs_lookahead || c->comm.nranks > 1 || c->g.cutlo || c->g.cuthi) return false;
+    if (c->per_j || c->pp_per_j || c->g.ni < 8 || c->g.nj < 4) return false;
+    if (c->fbc_class[CFD_SIDE_JMIN] != 2 || c->fbc_class[CFD_SIDE_JMAX] != 2) return false;
+    if (c->per_i) return c->fbc_class[CFD_SIDE_IMIN] == 1 && c->fbc_class[CFD_SIDE_IMAX] == 1 && c->wrap_p_i && c->pp_per_i;
+    return c->fbc_class[CFD_SIDE_IMIN] == 2 && c->fbc_class[CFD_SIDE_IMAX] == 2 && !c->pp_per_i;
+}
+
+// u*, v* in U1 / V1, snapshot in U / V / P (solver.py:1596-1598), p' (with its ghosts) in pcorr: leaves the corrected
+// fields in the planes that U1 / V1 / P1 name afterwards (u, v by rebinding two work planes), b_u, b_v of the next
+// iteration, the continuity sum and (laminar runs) the next step's time-step minima in the partial sums.
+// The caller flips c->cur, fills the memory ghosts (k_flow_bc) and reads the sums (finish_correct_flux).
+int launch_correct_flux(Ctx *c, double dt, double ru, double rv, double rp, bool *dt_too_out, int *nb_out) {
+    FluxMarch fm = flux_march_geo(c->g);
+    fm.nstrips = (c->g.ni + CFW - 1) / CFW;
+    {
+        const long nb = ((long)fm.nstrips * fm.nsegs + 3) / 4;
+        fm.blocks = (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
+    }
+    flux_march_widen(c, fm);
+    // lockstep workgroups of four strips (two workgroups per CU at this kernel's register count) measured against eight
+    const bool lock4 = fm.wide == 8 && c->cf_form == 2;
+    if (fm.wide == 8 && c->cf_form == 0) fm.wide = 4;
+    if (lock4 || fm.wide == 4) {
+        const long nb = lock4 ? (long)((fm.nstrips + 3) / 4) * fm.nsegs : ((long)fm.nstrips * fm.nsegs + 3) / 4;
+        fm.blocks = (int)(nb < MAX_PARTIALS ? nb : MAX_PARTIALS);
+        fm.wide = 4;
+    }
+    double *uo = c->kry[2], *vo = c->kry[3];
+    CorrIn ci{c->U1(), c->V1(), c->U(), c->V(), c->P(), c->pcorr, c->ap, uo, vo, c->P1(), ru, rv, rp, c->rhie_chow, c->per_i, c->nts()};
+    MomArgs ma{c->turbulent ? c->k : nullptr, c->ai, c->aj, 1.0 / dt, -c->dpdx, -c->dpdy, c->per_i, c->per_j, c->bu, c->bv};
+    ma.nts = c->nts();
+    c->kc[KC_FLUX_MARCH] += 1;
+    if (fm.nstrips > 1) c->kc[KC_FLUX_MARCH_MULTISTRIP] += 1;
+    c->kc[KC_CORRECT_FLUX] += 1;
+    const bool dt_too = c->dt_lookahead && c->dtp_set && (c->dtp_use_cfl || !c->turbulent);
+    // u*, v*, u0, v0, p0, p', a_P, V, w x 2, n x 4, S x 2 read; u, v, p, b_u, b_v written (+ k, + lmin)
+    c->last_rhs_bytes = 176.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0);
+    if (dt_too) {
+        ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
+        ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
+#define LAUNCH_CF(KGv, DTv)                                                                                                   \
+    do {                                                                                                                     \
+        if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+        else LAUNCH_FLUX(fm, (k_correct_flux<KGv, DTv, 4>), (k_correct_flux<KGv, DTv, 8>), c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials);                       \
+    } while (0)
+        if (c->turbulent) LAUNCH_CF(true, true);
+        else LAUNCH_CF(false, true);
+        hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials + MAX_PARTIALS, fm.blocks, 2,
+                           c->scal + DT_AHEAD_OFF);
+    } else if (c->turbulent) {
+        LAUNCH_CF(true, false);
+    } else {
+        LAUNCH_CF(false, false);
+    }
+    CFD_HIP(hipGetLastError());
+    // the corrected u, v become U1 / V1 (the planes that held u*, v* become work planes)
+    std::swap(c->u[c->cur ^ 1], c->kry[2]);
+    std::swap(c->v[c->cur ^ 1], c->kry[3]);
+    *dt_too_out = dt_too;
+    *nb_out = fm.blocks;
+    return CFD_OK;
+}
+
+// after c->cur has been flipped: the bookkeeping of launch_momentum_rhs's look-ahead and the read of the sums
+int finish_correct_flux(Ctx *c, bool dt_too, int nb, double *cont) {
+    if (dt_too) {
+        c->dt_ahead = true;
+        c->dt_ahead_diff = !c->turbulent;
+        c->dt_ahead_cur = c->cur;
+    }
+    return finish_continuity(c, nb, cont, dt_too);
 }
 
 // ----------------------------------------------------------------------------------

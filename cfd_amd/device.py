@@ -432,7 +432,7 @@ class Device:
 
     KERNEL_COUNT_NAMES = ("cheb4_2rhs", "cheb4_1rhs", "cheb2", "cheb1", "bicgstab_iters", "flux_march",
                           "flux_march_multistrip", "flux_tile", "mg_fused_levels_max", "mg_deferred_resid", "cg_pq",
-                          "vcycles", "mg_line_levels_max", "mg_tail_levels")
+                          "vcycles", "mg_line_levels_max", "mg_tail_levels", "correct_flux")
 
     def kernel_counts(self, reset=False):
         """Launches per kernel family since the last reset (include/cfd_hip.h: cfd_kernel_counts)."""

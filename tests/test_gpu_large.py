@@ -373,3 +373,60 @@ def test_lockstep_workgroups_match_independent_waves(turbulent, tmp_path):
         assert np.array_equal(log[:, 2], base[1][:, 2])
         assert np.all(np.abs(log[:, 3] - base[1][:, 3]) <= 1e-9 * base[1][:, 3] + 1e-14)
         assert last["stats"]["p_iters"] == base[2]["stats"]["p_iters"]
+
+
+def _run_pair(builder, fixup, tmp_path, extra=None):
+    """The same case with the correction fused into the closing flux pass (default) and with the separate kernels."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    runs = []
+    for fused in (1, 0):
+        cfg, mp, kind = builder()
+        work = tmp_path / f"f{fused}"
+        gen = hip_mesh.generate_rect_mesh if kind == "rect" else hip_mesh.generate_annulus_mesh
+        cfg["mesh"] = {"generator": gen, "params": mp, "path": work / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": work, "mesh_dir": work / "mesh", "states_dir": work / "states", "post_dir": work / "postproc"}
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        if fixup is not None:
+            fixup(cfg, mesh)
+        cfg["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
+        cfg["solver"]["momentum"]["tol"] = TRANSPORT_TOL
+        cfg["solver"]["tuning"] = dict({"mg_line": 0, "fuse_correct": fused}, **(extra or {}))
+        fields, step, time = hip_solver.run_case(cfg)
+        log = np.loadtxt(work / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+        runs.append((fields, log, dict(hip_solver.LAST_RUN)))
+    return runs
+
+
+def _wide_channel(turbulent):
+    cfg, mp, kind = cases.channel_forced(n=64, steps=3, turbulent=turbulent, ratio_j=1.0)
+    mp.update({"count_i": 1024, "length_i": 16.0 * mp["length_i"]})
+    for side, n in (("i_min", 64), ("i_max", 64), ("j_min", 1024), ("j_max", 1024)):
+        cfg["boundary"][side]["range"] = (0, n - 1)
+    return cfg, mp, kind
+
+
+FUSED_CORRECTION_CASES = {
+    "channel_forced_160x96": cases.LARGE_END_TO_END["channel_forced_160x96"],                  # periodic i, walls, three strips
+    "channel_forced_komega_160x96": cases.LARGE_END_TO_END["channel_forced_komega_160x96"],    # + grad(2/3 k)
+    "inlet_outlet_160x96": cases.LARGE_END_TO_END["inlet_outlet_160x96"],                      # ghost columns from the tables
+    "half_cylinder_132x24": (lambda: cases.half_cylinder(nr=132, nt=24, steps=3), None),       # symmetry rows, curvilinear
+    "half_cylinder_komega_132x24": (lambda: cases.half_cylinder(nr=132, nt=24, steps=3, turbulent=True), None),
+    "channel_1024x64": (lambda: _wide_channel(False), cases.perturbed_parabola),               # lockstep workgroups
+    "channel_komega_1024x64": (lambda: _wide_channel(True), cases.perturbed_parabola),
+}
+
+
+@pytest.mark.parametrize("name", list(FUSED_CORRECTION_CASES))
+def test_correction_fused_into_the_closing_flux_pass(name, tmp_path):
+    """k_correct_flux (velocity / pressure correction, ghost cells from the BC tables in registers, momentum right-hand
+    sides, continuity sum and time-step minima in one marching pass) against k_correct + k_flow_bc + k_flux_march<2>:
+    the same bits in every field; the continuity sum is taken over other strip widths (rounding)."""
+    builder, fixup = FUSED_CORRECTION_CASES[name]
+    (f1, log1, last1), (f0, log0, last0) = _run_pair(builder, fixup, tmp_path)
+    assert last1["kernel_counts"]["correct_flux"] > 0 and last0["kernel_counts"]["correct_flux"] == 0
+    for key in f0:
+        assert np.array_equal(mask_corners(f1[key]), mask_corners(f0[key])), key
+    assert np.array_equal(log1[:, [0, 2]], log0[:, [0, 2]])
+    assert np.all(np.abs(log1[:, 3] - log0[:, 3]) <= 1e-11 * log0[:, 3] + 1e-300)
+    assert last1["stats"]["p_iters"] == last0["stats"]["p_iters"]

@@ -45,6 +45,9 @@ def algo_of(k):
     m = re.match(r"k_mg_down_k<true, 3, (true|false)", k)
     if m:
         return 50 if m.group(1) == "true" else 34
+    m = re.match(r"k_correct_flux<(true|false), (true|false)", k)
+    if m:       # correction + ghost cells + momentum right-hand sides: 17 planes read, 5 written (+ k, + lmin)
+        return 176 + (8 if m.group(1) == "true" else 0) + (8 if (m.group(2) == "true" and m.group(1) != "true") else 0)
     m = re.match(r"k_flux_march<(\d), (true|false)(?:, (true|false))?", k)
     if m:
         mode, kg, dt = m.group(1), m.group(2) == "true", m.group(3) == "true"
