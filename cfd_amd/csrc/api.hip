@@ -1371,14 +1371,6 @@ int cfd_probe(cfd_ctx *ctx, int kernel) {
             CFD_HIP(hipEventCreate(&c->probe_e0[q]));
             CFD_HIP(hipEventCreate(&c->probe_e1[q]));
         }
-        // an event gets its completion signal at its first record: record every new event once now, so that the timed
-        // launches do not pay for that (the first process on a fresh machine measured 3.7 ms per step more than later
-        // ones with identical kernel times)
-        for (size_t q = have; q < want; ++q) {
-            CFD_HIP(hipEventRecord(c->probe_e0[q], c->stream));
-            CFD_HIP(hipEventRecord(c->probe_e1[q], c->stream));
-        }
-        CFD_HIP(hipStreamSynchronize(c->stream));
     }
     c->probe_kernel = kernel;
     c->probe_n = 0;
