@@ -120,6 +120,7 @@ SIGNATURES = {
     "cfd_probe_read_id": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), _dp, _dp]),
     "cfd_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "cfd_host_counters": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
+    "cfd_host_syncs_by_phase": (C.c_int, [C.POINTER(C.c_longlong), C.c_int]),
     "cfd_kernel_counts": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.c_int, C.c_int]),
     "cfd_phase_times": (C.c_int, [_vp, _dp, C.c_int]),
     "cfd_enable_phase_timing": (C.c_int, [_vp, C.c_int]),

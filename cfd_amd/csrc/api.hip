@@ -10,7 +10,8 @@
 namespace cfd {
 
 static thread_local char g_err[1024] = "";
-long long g_launches = 0, g_syncs = 0;
+long long g_launches = 0, g_syncs = 0, g_syncs_phase[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_phase = 8;
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -642,6 +643,12 @@ int cfd_host_counters(long long out[2], int reset) {
     return CFD_OK;
 }
 
+int cfd_host_syncs_by_phase(long long out[9], int reset) {
+    if (!out) return CFD_E_ARG;
+    for (int q = 0; q < 9; ++q) { out[q] = cfd::g_syncs_phase[q]; if (reset) cfd::g_syncs_phase[q] = 0; }
+    return CFD_OK;
+}
+
 int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset) {
     CTX(ctx);
     if (!counts || n < 1) { set_error("cfd_kernel_counts: bad arguments"); return CFD_E_ARG; }
@@ -792,12 +799,15 @@ struct Phase {
     Ctx *c;
     int id;
     int outer;
-    Phase(Ctx *c_, int id_) : c(c_), id(id_), outer(c_->comm.phase) {
+    int outer_g;
+    Phase(Ctx *c_, int id_) : c(c_), id(id_), outer(c_->comm.phase), outer_g(g_phase) {
         c->comm.phase = id;
+        g_phase = id;
         if (c->timing) hipEventRecord(c->ev0, c->stream);
     }
     ~Phase() {
         c->comm.phase = outer;
+        g_phase = outer_g;
         if (!c->timing) return;
         hipEventRecord(c->ev1, c->stream);
         hipEventSynchronize(c->ev1);

@@ -88,14 +88,15 @@ void set_error(const char *fmt, ...);
 
 // host-side cost counters (cfd_host_counters): kernel launches and blocking stream synchronisations issued by the
 // library in this process -- the two quantities that bound the step time of small meshes and of thin j-slabs
-extern long long g_launches, g_syncs;
+extern long long g_launches, g_syncs, g_syncs_phase[9];      // [phase id of api.hip's Phase, 8 = outside any phase]
+extern int g_phase;
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                    \
     do {                                                                               \
         ++cfd::g_launches;                                                             \
         kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                   \
     } while (0)
-#define hipStreamSynchronize(stream) (++cfd::g_syncs, (hipStreamSynchronize)(stream))
+#define hipStreamSynchronize(stream) (++cfd::g_syncs, ++cfd::g_syncs_phase[cfd::g_phase], (hipStreamSynchronize)(stream))
 
 #define CFD_HIP(expr)                                                                         \
     do {                                                                                      \

@@ -87,6 +87,7 @@ int read_scalars_begin(Ctx *c, int off, int n) {
     return CFD_OK;
 }
 int read_scalars_end(Ctx *c, int off, int n, double *host) {
+    ++g_syncs_phase[g_phase];
     ++g_syncs;       // counted like a stream synchronisation (the host blocks), though the GPU need not drain
     CFD_HIP(hipEventSynchronize(c->ev_read));
     for (int q = 0; q < n; ++q) host[q] = c->h_scal[off + q];

@@ -446,6 +446,14 @@ class Device:
         check(self.lib.cfd_host_counters(out, int(reset)))
         return int(out[0]), int(out[1])
 
+    SYNC_PHASES = ("bc", "adv", "mom", "press", "corr", "cont", "turb", "dt", "other")
+
+    def host_syncs_by_phase(self, reset=False):
+        """Blocking stream synchronisations of the library in this process by the phase that issued them."""
+        out = (C.c_longlong * 9)()
+        check(self.lib.cfd_host_syncs_by_phase(out, int(reset)))
+        return dict(zip(self.SYNC_PHASES, [int(v) for v in out]))
+
     def enable_phase_timing(self, on=True):
         check(self.lib.cfd_enable_phase_timing(self._h, int(on)))
 

@@ -410,12 +410,17 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
  * launches, [3] 1-iteration launches, [4] BiCGStab iterations, [5] marching flux launches, [6] of those with more
  * than one column strip, [7] tile flux launches, [8] max number of fused multigrid levels in a V-cycle, [9] PCG
  * iterations whose residual update ran inside the pre-smoother, [10] fused PCG direction steps, [11] V-cycles,
- * [12] max number of levels smoothed by j-lines.  n <= 16 entries are written.  No counterpart in the reference.  */
+ * [12] max number of line-smoothed levels, [13] levels cycled by the single-launch V-cycle tail, [14] launches of the fused
+ * correction / flux kernel.  n <= 16 entries are written.  No counterpart in the reference.  */
 int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset);
 /* Host-side cost of the calls so far, process wide: out[0] = kernel launches, out[1] = blocking stream
  * synchronisations the library issued (each one idles the GPU while the host reads a scalar).  They bound the step
  * time of small meshes and thin j-slabs (tools/small_mesh_timing.py).  No counterpart in the reference.            */
 int cfd_host_counters(long long out[2], int reset);
+/* the blocking synchronisations of cfd_host_counters by the phase of the step that issued them: [0] boundary conditions,
+ * [1] coefficients / right-hand sides, [2] momentum solves, [3] pressure solve, [4] correction, [5] continuity / closing
+ * pass, [6] turbulence update, [7] time step, [8] outside any phase.  No counterpart in the reference.                  */
+int cfd_host_syncs_by_phase(long long out[9], int reset);
 /* accumulated device time per phase since the last reset (HIP events), microseconds:
  * {bc, adv(rhs), mom, press, corr, cont, turb, dt}                                          */
 int cfd_phase_times(cfd_ctx *ctx, double out[8], int reset);

@@ -430,3 +430,18 @@ def test_correction_fused_into_the_closing_flux_pass(name, tmp_path):
     assert np.array_equal(log1[:, [0, 2]], log0[:, [0, 2]])
     assert np.all(np.abs(log1[:, 3] - log0[:, 3]) <= 1e-11 * log0[:, 3] + 1e-300)
     assert last1["stats"]["p_iters"] == last0["stats"]["p_iters"]
+
+
+@pytest.mark.parametrize("shape", [(8, 4), (59, 7), (60, 8), (61, 9), (120, 16), (121, 33), (180, 5)])
+@pytest.mark.parametrize("kind", ["periodic", "inlet_outlet"])
+def test_fused_correction_at_strip_and_segment_edges(kind, shape, tmp_path):
+    """Mesh sizes around the 60-column strips and the row segments of k_correct_flux (one strip exactly full, one cell
+    more, the smallest mesh the fused pass takes, fewer rows than a segment): the same bits as the separate kernels."""
+    ni, nj = shape
+    builder = (lambda: cases.lam_channel(ni, nj, steps=3)) if kind == "periodic" else (lambda: cases.inlet_outlet_channel(ni, nj, steps=3))
+    (f1, log1, last1), (f0, log0, last0) = _run_pair(builder, None, tmp_path)
+    assert last1["kernel_counts"]["correct_flux"] > 0 and last0["kernel_counts"]["correct_flux"] == 0
+    for key in f0:
+        assert np.array_equal(mask_corners(f1[key]), mask_corners(f0[key])), key
+    assert np.array_equal(log1[:, [0, 2]], log0[:, [0, 2]])
+    assert np.all(np.abs(log1[:, 3] - log0[:, 3]) <= 1e-11 * log0[:, 3] + 1e-300)

@@ -17,6 +17,7 @@ for n, turb in ((32, False), (64, False), (128, False), (256, False), (512, Fals
         step += 1
     dev.synchronize()
     dev.host_counters(reset=True)
+    dev.host_syncs_by_phase(reset=True)
     k = 20
     per_step = []
     for _ in range(k):
@@ -31,5 +32,5 @@ for n, turb in ((32, False), (64, False), (128, False), (256, False), (512, Fals
     st = dev.stats()
     print(json.dumps({"n": n, "turbulent": turb, "ms_per_step": round(ms, 3), "ms_mean": round(sum(per_step) / k, 3), "cells_per_s": round(n * n / ms * 1e3),
                       "launches_per_step": round(launches / k, 1), "syncs_per_step": round((syncs - k) / k, 1),
-                      "mom_iters": st["mom_iters"], "p_iters": st["p_iters"], "k_iters": st["k_iters"]}), flush=True)
+                      "syncs_by_phase": {k: round(v / k_, 1) for k, v in dev.host_syncs_by_phase().items() if v} if (k_ := k) else {}, "mom_iters": st["mom_iters"], "p_iters": st["p_iters"], "k_iters": st["k_iters"]}), flush=True)
     dev.close()
