@@ -625,6 +625,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "mg_om0" || n == "mg_om1" || n == "mg_om2") { if (!(value > 0.0 && value <= 1.5)) { set_error("mg_om*: (0, 1.5]"); return CFD_E_ARG; } c->mg_om[n[5] - '0'] = value; }
     else if (n == "xcd_map") c->xcd_map = iv ? 1 : 0;
     else if (n == "fuse_correct") c->fuse_correct = iv ? 1 : 0;
+    else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "wide_mask") { if (iv < 0 || iv > 1023) { set_error("wide_mask: 0 .. 1023"); return CFD_E_ARG; } c->wide_mask = iv; }
     else if (n == "mg_tail") { c->mg_tail = iv ? 1 : 0; c->p_built = false; }

@@ -297,6 +297,8 @@ struct Ctx {
     bool fbc_set[4] = {false, false, false, false};
     int fbc_class[4] = {0, 0, 0, 0};   // 1: every entry periodic (u, v and p); 2: every entry AFFINE / SYMMETRY (u, v) and AFFINE (p); 0: anything else
     int cf_form = 2;                   // k_correct_flux on meshes of >= 16 strips: 0 independent waves, 1 lockstep workgroups of 8 strips, 2 of 4
+    double p_sym_tol = 1.0e-5;         // relative seam asymmetry of the frozen pressure operator up to which it is solved by PCG
+    double p_seam_asym = 0.0;          // the measured one (diagnostic)
     int fuse_correct = 1;              // correction + boundary fill + closing flux pass in one marching kernel where correct_flux_ok()
     int per_i = 0, per_j = 0, wrap_p_i = 0, wrap_p_j = 0;
     int32_t *pmask[4] = {nullptr, nullptr, nullptr, nullptr};

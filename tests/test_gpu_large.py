@@ -247,11 +247,13 @@ def test_multistrip_kernels_against_reference_vectors(tag, marching):
 # ---------------------------------------------------------------------------------------------------------------------
 # stretched meshes: alternating line smoother (the reference's real cases are wall-graded, Runs/*/config.py ratio_j 1.03)
 # ---------------------------------------------------------------------------------------------------------------------
-def _krylov_case(mesh, bc, per_i, per_j, mode, tol=1e-8):
+def _krylov_case(mesh, bc, per_i, per_j, mode, tol=1e-8, options=None):
     from test_gpu_parity import _device_for
     ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
     dev = _device_for(mesh, bc, 1e-3, turbulent=False)
     dev.set_option("mg_line", mode)
+    for name, value in (options or {}).items():
+        dev.set_option(name, value)
     dev.upload_fields({k: np.zeros((ni + 2, nj + 2)) for k in ("u", "v", "p", "nu_t")})
     dev.momentum_diagonal(3e-3, 1.0)
     ci, cj, diag, _ = dev.pressure_system()
@@ -445,3 +447,22 @@ def test_fused_correction_at_strip_and_segment_edges(kind, shape, tmp_path):
         assert np.array_equal(mask_corners(f1[key]), mask_corners(f0[key])), key
     assert np.array_equal(log1[:, [0, 2]], log0[:, [0, 2]])
     assert np.all(np.abs(log1[:, 3] - log0[:, 3]) <= 1e-11 * log0[:, 3] + 1e-300)
+
+
+@pytest.mark.parametrize("ratio_i,expect", [(1.0 + 1.0e-8, "pcg"), (1.02, "fallback")])
+def test_nearly_symmetric_seam_goes_through_pcg_with_a_fallback(ratio_i, expect):
+    """A periodic seam whose two coefficient copies differ by more than rounding (the reference's centroid formula loses
+    digits on thin cells: 1e-6 on the wall-graded 8192^2 mesh; here a mesh graded by 1e-8 per cell along the periodic
+    axis) is solved by MG-PCG, one V-cycle per iteration, as long as the relative difference stays below p_sym_tol;
+    a strongly graded periodic axis pushed through the same door (p_sym_tol = 1e-2) either converges or is handed to
+    MG-BiCGStab from the saved right-hand side -- the true residual meets the tolerance either way."""
+    from test_gpu_parity import _bc_variant
+    mesh = orc.rect_mesh(1.0, 1.0, 192, 96, ratio_i, 1.02)
+    bc = _bc_variant("per_i", 192, 96)
+    opts = {} if expect == "pcg" else {"p_sym_tol": 1.0e-2}
+    it, rr, res, levels, solver = _krylov_case(mesh, bc, True, False, 0, options=opts)
+    it_b, rr_b, res_b, _, solver_b = _krylov_case(mesh, bc, True, False, 0, options={"p_sym_tol": 0.0})
+    assert solver_b == "mg-bicgstab" and res_b <= 2e-8
+    assert res <= 2e-8 and rr <= 1e-8, (res, rr, it, solver)
+    if expect == "pcg":
+        assert solver == "mg-pcg" and it <= 2 * it_b + 2, (it, it_b)
