@@ -607,7 +607,8 @@ def test_residual_update_inside_the_presmoother(name, tmp_path):
 @pytest.mark.parametrize("turbulent", [False, True])
 def test_all_fusions_together_keep_the_bits_over_many_steps(turbulent):
     """The bench workload at 512^2 for 40 outer steps: eddy viscosity inside the conductance pass, time-step minima and
-    momentum right-hand sides taken ahead, PCG residual update inside the pre-smoother -- all on vs all off gives the
+    momentum right-hand sides taken ahead, PCG residual update inside the pre-smoother, correction inside the closing
+    flux pass -- all on vs all off gives the
     same u, v, p, k, omega, nu_t bit for bit and the same time."""
     import bench
     from cfd_amd import _lib as L
@@ -615,7 +616,7 @@ def test_all_fusions_together_keep_the_bits_over_many_steps(turbulent):
     out = {}
     for mode in ("0", "1"):
         tuning = {"fuse_nut": int(mode), "dt_lookahead": int(mode), "fuse_resid": int(mode), "cheb_prefetch": 1 + int(mode),
-                  "nt_stores": int(mode)}
+                  "nt_stores": int(mode), "fuse_correct": int(mode)}
         dev, ctl, cfg = bench.setup_device(512, turbulent, 2, 1e-8, 0, tuning=tuning, lookahead=bool(int(mode)))
         t = 0.0
         for step in range(40):
