@@ -1469,12 +1469,13 @@ __global__ void k_turb_rhs(Geo g, MeshDev m, FluxIn f, const double *om, const d
 int launch_turb_rhs(Ctx *c, double dt) {
     FluxIn f{c->U(), c->V(), c->P(), c->k, c->ap, c->rhie_chow};
     if (c->march_flux) {
-        const FluxMarch fm = flux_march_geo(c->g);
+        FluxMarch fm = flux_march_geo(c->g);
+        flux_march_widen(c, fm);
         MomArgs ma{c->k, c->ti, c->tj, 1.0 / dt, 0.0, 0.0, c->per_i, c->per_j, c->bu, c->bv};
         ma.nts = c->nts();
         ma.nut = c->nut; ma.omega = c->omega;
-        hipLaunchKernelGGL((k_flux_march<4, false>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), f, fm, ma,
-                           (double *)nullptr, c->partials);
+        LAUNCH_FLUX(fm, (k_flux_march<4, false>), (k_flux_march<4, false, false, 8>), c->g, c->mesh(), f, fm, ma,
+                    (double *)nullptr, c->partials);
         CFD_HIP(hipGetLastError());
         return CFD_OK;
     }
