@@ -163,7 +163,9 @@ int cfd_level_smoother(cfd_ctx *ctx, int level, int *ni, int *nj, double *aniso,
 int cfd_set_stream(cfd_ctx *ctx, void *hip_stream);
 int cfd_synchronize(cfd_ctx *ctx);
 int cfd_pitch(cfd_ctx *ctx);                       /* row pitch in doubles          */
-/* byte offset of a field plane inside the workspace (for zero-copy host views)     */
+/* byte offset of a field plane inside the workspace (for zero-copy host views).  Ask again after every step: the
+ * library rebinds plane pointers instead of copying planes (the u, v ping-pong of a SIMPLE iteration, Chebyshev and
+ * correction results that become u*, v*, k, omega), so the plane that holds a field changes over a run.            */
 int64_t cfd_field_offset(cfd_ctx *ctx, int field_id);
 
 /* ---- mesh (data contract of mesh.precompute_from_nodes, mesh.py:186-399) -------- */
@@ -310,7 +312,8 @@ int cfd_bulk_velocity(cfd_ctx *ctx, int field_id, double *out);
  * loops, harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE (its bulk velocity is one numpy line,
  * post_processing.py:602-610).  Allocates nothing (no hipMalloc / hipFree, no allocating library routine), takes
  * no context: field_dev and volume_dev are device planes in the library's layout -- cell (i, j) at
- * (j + CFD_GHOST_ROWS) * pitch + i + 2, pitch >= ni + 4 doubles -- e.g. workspace + cfd_field_offset(ctx, id);
+ * (j + CFD_GHOST_ROWS) * pitch + i + CFD_COL_OFFSET, pitch >= ni + CFD_COL_OFFSET + 2 doubles -- e.g. workspace +
+ * cfd_field_offset(ctx, id);
  * out_dev receives three doubles ON THE DEVICE: {sum f V / sum V, sum f V, sum V}; both kernels are enqueued on
  * hip_stream (NULL = the default stream) of the CURRENT device and the call returns without synchronising.  The
  * partial sums live in a fixed 64 KiB device array of the library (one copy per GPU, held until the process ends):
