@@ -466,3 +466,24 @@ def test_nearly_symmetric_seam_goes_through_pcg_with_a_fallback(ratio_i, expect)
     assert res <= 2e-8 and rr <= 1e-8, (res, rr, it, solver)
     if expect == "pcg":
         assert solver == "mg-pcg" and it <= 2 * it_b + 2, (it, it_b)
+
+
+def test_fused_correction_at_the_benchmark_size():
+    """BASELINE.json's 8192^2 workload, three outer steps: the fused correction / flux kernel (lockstep workgroups of four
+    strips, 137 strips, 256 segments) leaves the same bits in u, v, p as the three kernels it replaces, and the run takes
+    the same iteration counts."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for fused in (1, 0):
+        dev, ctl, cfg = bench.setup_device(8192, False, 2, 1e-8, 0, tuning={"fuse_correct": fused})
+        for step in range(3):
+            advance_one_step(dev, ctl, step)
+        kc = dev.kernel_counts()
+        out[fused] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P)], dev.stats(), kc)
+        dev.close()
+    assert out[1][2]["correct_flux"] == 6 and out[0][2]["correct_flux"] == 0
+    for a, b in zip(out[1][0], out[0][0]):
+        assert np.array_equal(mask_corners(a), mask_corners(b))
+    assert out[1][1]["p_iters"] == out[0][1]["p_iters"] and out[1][1]["mom_iters"] == out[0][1]["mom_iters"]
