@@ -496,8 +496,10 @@ def main():
         # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes of one
         # MG-PCG iteration over all levels: finest level 64 (k_cg_pq) + 24 (k_cg_r) + 34 (k_mg_down)
         # + 42 (k_mg_up) B/cell (diagonal recomputed from the face planes on every level of this all-Neumann /
-        # periodic system), coarser levels (34 + 42) / 3 B/cell.
-        pcg_bytes_per_cell_iter = 64 + 24 + 34 + 42 + (34 + 42) / 3.0
+        # periodic system), coarser levels (34 + 42) / 3 B/cell.  With the single-precision face planes of the fused
+        # V-cycle kernels (option mg_f32, default on) each of the two passes reads 8 B per cell less.
+        f32 = 0.0 if "mg_f32=0" in (args.tuning or "").replace(" ", "") else 8.0
+        pcg_bytes_per_cell_iter = 64 + 24 + (34 - f32) + (42 - f32) + ((34 - f32) + (42 - f32)) / 3.0
         n_solves = extra_steps * args.max_iter
         press_s = phases["press"] / n_solves
         mean_p_it = float(np.mean(p_its))

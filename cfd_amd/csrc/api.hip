@@ -340,6 +340,7 @@ int cfd_destroy(cfd_ctx *ctx) {
     if (c->own_ws && c->ws) hipFree(c->ws);
     if (c->sst_mem) hipFree(c->sst_mem);
     if (c->line_mem) hipFree(c->line_mem);
+    if (c->f32_mem) hipFree(c->f32_mem);
     if (c->wall_xy) hipFree(c->wall_xy);
     delete ctx;
     return CFD_OK;
@@ -630,6 +631,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "wide_mask") { if (iv < 0 || iv > 1023) { set_error("wide_mask: 0 .. 1023"); return CFD_E_ARG; } c->wide_mask = iv; }
     else if (n == "mg_tail") { c->mg_tail = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
+    else if (n == "mg_v32_emul") c->mg_v32_emul = iv ? 1 : 0;
+    else if (n == "mg_f32") { c->mg_f32 = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_dirs") { c->mg_line_dirs = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }
     else if (n == "mg_line_omega") { if (!(value > 0.0 && value <= 1.0)) { set_error("mg_line_omega: (0, 1]"); return CFD_E_ARG; } c->mg_line_omega = value; }

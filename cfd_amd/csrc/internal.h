@@ -64,6 +64,9 @@ struct OpDev {
     const double *ci, *cj, *D;
     Geo g;
     int per_i, per_j;
+    // single-precision copies of the face planes: read by the fused V-cycle kernels only (the preconditioner of the
+    // pressure Krylov solve stays a fixed symmetric operator; the Krylov operator itself is ci / cj); null: none
+    const float *cif, *cjf;
 };
 
 // finest pressure level: diagonal recomputed from the face planes (linalg.hip, diag_from_faces);
@@ -200,6 +203,7 @@ struct Level {
     // j-blocks (Thomas multipliers and inverse pivots), computed when the hierarchy is built
     bool line = false;
     int line_dirs = 0;            // bit 0: j-lines, bit 1: i-lines
+    float *cif = nullptr, *cjf = nullptr;         // see OpDev
     double *lm = nullptr, *linv = nullptr;        // j-blocks
     double *lmi = nullptr, *linvi = nullptr;      // i-blocks
     double aniso = 1.0;           // max over the cells of strong / weak coupling (diagnostic, cfd_level_aniso)
@@ -362,6 +366,10 @@ struct Ctx {
     char *sst_mem = nullptr;
     char *line_mem = nullptr;      // Thomas factor planes of the line-smoothed multigrid levels (own allocation)
     size_t line_mem_bytes = 0;
+    char *f32_mem = nullptr;       // single-precision face planes of the fused multigrid levels (own allocation)
+    size_t f32_mem_bytes = 0;
+    int mg_v32_emul = 0;
+    int mg_f32 = 1;                // fused V-cycle levels read their face coefficients in single precision
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
     int mg_line_dirs = 1;          // 1: a line-smoothed level sweeps both directions; 0: only those whose own coupling ratio exceeds the threshold (wall-graded 8192^2 channel: 79 iterations instead of 12, the wide centre cells need the i-lines)
     double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this

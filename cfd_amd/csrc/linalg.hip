@@ -1076,7 +1076,7 @@ struct ResidFuse {
     double *rnew;
 };
 
-template <bool UP, bool RF = false, bool XO = false>
+template <bool UP, bool RF = false, bool XO = false, bool F32 = false>
 __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, const Geo &g, const Geo &gc, const double *b,
                                          const double *x, const double *e, int j, bool cvalid, size_t colo, size_t coloc,
                                          MgRaw &R, const double *q = nullptr) {
@@ -1090,9 +1090,14 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
         R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
     if (XO) R.x = x[cc];
-    R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
+    R.b = b[cc];
     if (RF) R.q = q[cc];
-    R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
+    const size_t cn_at = cc + (mr < g.nj + 2 * NG - 1 ? P : 0);
+    if (F32) {
+        R.cw = op.cif[cc]; R.ce = op.cif[cc + 1]; R.cs = op.cjf[cc]; R.cn = op.cjf[cn_at];
+    } else {
+        R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc]; R.cn = op.cj[cn_at];
+    }
     R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
     R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
 }
@@ -1101,7 +1106,7 @@ __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const 
     return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
 }
 
-template <bool FINE, int K, bool RF = false, int WPB = 4>
+template <bool FINE, int K, bool RF = false, int WPB = 4, bool F32 = false>
 __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
                                                         Geo gc, double *bc, ResidFuse rf = ResidFuse{}, int nts = 0) {
     const Geo g = op.g;
@@ -1132,16 +1137,16 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
         }
         double rsum = 0.0;
         MgRaw nxt;
-        mg_fetch<false, RF>(op, df, g, gc, b, nullptr, nullptr, j0 - K, cvalid, colo, 0, nxt, rf.q);
+        mg_fetch<false, RF, false, F32>(op, df, g, gc, b, nullptr, nullptr, j0 - K, cvalid, colo, 0, nxt, rf.q);
         for (int j = j0 - K; j < j1 + K; ++j) {
             MgRaw cur = nxt;
-            if (j + 1 < j1 + K) mg_fetch<false, RF>(op, df, g, gc, b, nullptr, nullptr, j + 1, cvalid, colo, 0, nxt, rf.q);
+            if (j + 1 < j1 + K) mg_fetch<false, RF, false, F32>(op, df, g, gc, b, nullptr, nullptr, j + 1, cvalid, colo, 0, nxt, rf.q);
             if (RF) {
                 cur.b = cur.b - alpha * cur.q;                               // k_cg_r's expression
                 // own rows, and at a slab cut the ghost rows next to the first / last segment (formed from the neighbour's
                 // r_old and q rows, they are the neighbour's r): the way up reads them
                 const bool own = (j >= j0 && j < j1) || (g.cutlo && j < 0 && j0 == 0) || (g.cuthi && j >= g.nj && j1 == g.nj);
-                if (own && out) store_stream(rf.rnew + (size_t)(j + NG) * P + colo, cur.b, nts);
+                if (own && out) store_stream(rf.rnew + (size_t)(j + NG) * P + colo, cur.b, nts & 1);
             }
             RC[0] = mg_row(cur, df, op, colo);
             V[0] = cur.valid;
@@ -1153,7 +1158,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
                 X[s2][2] = xn;
                 if (s2 == K) {
                     const int row = j - (K - 1);
-                    if (row >= j0 && row < j1 && out) store_stream(x + (size_t)(row + NG) * P + colo, xn, nts);
+                    if (row >= j0 && row < j1 && out) store_stream(x + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)xn : xn, nts & 1);
                 }
             }
             // residual on row j - K, summed over 2 x 2 aggregates into the coarse right-hand side
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
                 rsum += res;
                 if (((jo - j0) & 1) || jo == j1 - 1) {
                     const double tot = rsum + lane_right(rsum);
-                    if (out && !((lane - K) & 1)) bc[gc.cell(iraw >> 1, jo >> 1)] = (iraw + 1 < g.ni) ? tot : rsum;
+                    if (out && !((lane - K) & 1)) { const double cv = (iraw + 1 < g.ni) ? tot : rsum; bc[gc.cell(iraw >> 1, jo >> 1)] = (nts & 2) ? (double)(float)cv : cv; }
                     rsum = 0.0;
                 }
             }
@@ -1176,7 +1181,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
     }
 }
 
-template <bool FINE, int K, int WPB = 4>
+template <bool FINE, int K, int WPB = 4, bool F32 = false>
 __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
                                                       const double *e, double gamma, SweepOm<K> om, double *xn, double *partials, int nts = 0) {
     const Geo g = op.g;
@@ -1207,10 +1212,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
             X[s2][0] = 0.0; X[s2][1] = 0.0; X[s2][2] = 0.0;
         }
         MgRaw nxt;
-        mg_fetch<true>(op, df, g, gc, b, x, e, j0 - K, cvalid, colo, coloc, nxt);
+        mg_fetch<true, false, false, F32>(op, df, g, gc, b, x, e, j0 - K, cvalid, colo, coloc, nxt);
         for (int j = j0 - K; j < j1 + K; ++j) {
             const MgRaw cur = nxt;
-            if (j + 1 < j1 + K) mg_fetch<true>(op, df, g, gc, b, x, e, j + 1, cvalid, colo, coloc, nxt);
+            if (j + 1 < j1 + K) mg_fetch<true, false, false, F32>(op, df, g, gc, b, x, e, j + 1, cvalid, colo, coloc, nxt);
             RC[0] = mg_row(cur, df, op, colo);
             V[0] = cur.valid;
             X[0][2] = cur.valid ? cur.x + gamma * cur.e : 0.0;              // prolongated iterate on row j
@@ -1222,7 +1227,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
                 if (s2 == K) {
                     const int row = j - K;
                     if (row >= j0 && row < j1 && out) {
-                        store_stream(xn + (size_t)(row + NG) * P + colo, v, nts);
+                        store_stream(xn + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)v : v, nts & 1);
                         if (FINE) dot += RC[K].b * v;
                     }
                 }
@@ -2399,6 +2404,27 @@ int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *con
 static inline OpDev level_op(const Ctx *c, const Level &L) {
     return OpDev{L.ci, L.cj, L.D, L.g, c->pp_per_i, c->pp_per_j};
 }
+// operator of a fused V-cycle level: with the single-precision face planes where the level has them
+static inline OpDev level_op_mg(const Ctx *c, const Level &L) {
+    OpDev op = level_op(c, L);
+    if (c->mg_f32 && L.cif) { op.cif = L.cif; op.cjf = L.cjf; }
+    return op;
+}
+// face planes of a coarse level rounded in place to single-precision values: whichever kernel cycles the level (fused
+// marching kernels on the copies below, the LDS tail, the one-sweep kernels, the line smoother) then sees one operator,
+// and the V-cycle does not depend on where the tail starts or on the slab decomposition
+__global__ void k_round_faces_f32(double *ci, double *cj, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        ci[q] = (double)(float)ci[q];
+        cj[q] = (double)(float)cj[q];
+    }
+}
+__global__ void k_faces_to_f32(const double *ci, const double *cj, float *cif, float *cjf, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        cif[q] = (float)ci[q];
+        cjf[q] = (float)cj[q];
+    }
+}
 static inline void factors(const Geo &f, const Geo &co, int &fi, int &fj) {
     fi = (co.ni == f.ni) ? 1 : 2;
     fj = (co.nj == f.nj) ? 1 : 2;
@@ -2491,6 +2517,11 @@ int build_pressure_hierarchy(Ctx *c) {
         // C.t is used as the scratch for the diagonal extra
         hipLaunchKernelGGL(k_mg_coarsen, dim3(Tc.blocks), block2d(), 0, st, F.g, F.ci, F.cj, F.D, cg, Tc, fi, fj, ci_t,
                            cj_t, C.t);
+        if (c->mg_f32) {
+            // before the diagonal is summed from them: D stays the exact sum of the faces every kernel reads
+            const size_t n = cg.plane_elems();
+            hipLaunchKernelGGL(k_round_faces_f32, dim3((int)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, ci_t, cj_t, n);
+        }
         hipLaunchKernelGGL(k_mg_coarse_diag, dim3(Tc.blocks), block2d(), 0, st, cg, Tc, ci_t, cj_t, C.t, D_t);
         CFD_HIP(hipGetLastError());
         if (to_agg) {
@@ -2605,6 +2636,43 @@ int build_pressure_hierarchy(Ctx *c) {
             }
         }
     }
+    // ---- single-precision face planes of the levels the fused marching kernels cycle.  The V-cycle built on them is
+    // still one fixed symmetric operator (faces are stored once per pair of cells, the diagonal of the nullspace form is
+    // the sum of the same rounded faces), which is all PCG asks of its preconditioner: the solve converges to the
+    // solution of the double-precision operator as before, and each fused pass reads 8 B per cell less.
+    {
+        const int nl = (int)c->levels.size();
+        const int n_top = c->tail_lt > 0 ? c->tail_lt : nl - 1;
+        size_t need = 0;
+        std::vector<char> want(nl, 0);
+        for (int l = 0; l < nl; ++l) {
+            c->levels[l].cif = c->levels[l].cjf = nullptr;
+            // (every point-smoothed level above the tail: whether a level is cycled by the fused kernels can change with
+            // cfd_set_multigrid, which does not rebuild the hierarchy)
+            if (!c->mg_f32 || l >= n_top || c->levels[l].line) continue;
+            want[l] = 1;
+            need += 2 * ((c->levels[l].g.plane_elems() * sizeof(float) + 255) / 256 * 256);
+        }
+        if (need > c->f32_mem_bytes) {
+            if (c->f32_mem) CFD_HIP(hipFree(c->f32_mem));
+            c->f32_mem = nullptr;
+            c->f32_mem_bytes = 0;
+            CFD_HIP(hipMalloc((void **)&c->f32_mem, need));
+            c->f32_mem_bytes = need;
+        }
+        size_t off = 0;
+        for (int l = 0; l < nl; ++l) {
+            if (!want[l]) continue;
+            Level &L = c->levels[l];
+            const size_t n = L.g.plane_elems(), pb = (n * sizeof(float) + 255) / 256 * 256;
+            L.cif = (float *)(c->f32_mem + off);
+            L.cjf = (float *)(c->f32_mem + off + pb);
+            off += 2 * pb;
+            const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_faces_to_f32, dim3(nb), dim3(256), 0, st, L.ci, L.cj, L.cif, L.cjf, n);
+            CFD_HIP(hipGetLastError());
+        }
+    }
     c->p_built = true;
     return CFD_OK;
 }
@@ -2649,6 +2717,13 @@ static int line_smooth(Ctx *c, const Level &L, const OpDev &op, const double *rh
     do {                                                                                 \
         if ((wide) == 8) hipLaunchKernelGGL(K8, grid, dim3(512), 0, st, __VA_ARGS__);   \
         else hipLaunchKernelGGL(K4, grid, dim3(256), 0, st, __VA_ARGS__);               \
+    } while (0)
+
+// same, with the single-precision face planes where the level has them (K4F / K8F)
+#define LAUNCH_WIDE_F(f32, wide, K4, K8, K4F, K8F, grid, ...)                            \
+    do {                                                                                 \
+        if (f32) LAUNCH_WIDE(wide, K4F, K8F, grid, __VA_ARGS__);                         \
+        else LAUNCH_WIDE(wide, K4, K8, grid, __VA_ARGS__);                               \
     } while (0)
 
 // line-smoothed level whose point sweep is fused with the grid transfers (k_mg_down_x, k_mg_up_k<false, 1>)
@@ -2696,7 +2771,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     for (int l = 0; l < n_top; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
-        const OpDev op = level_op(c, L);
+        const OpDev op = level_op(c, L), opm = level_op_mg(c, L);
         const bool to_agg = la > 0 && l + 1 == la;
         const Geo cg = coarse_view(c, l + 1);
         double *cb = to_agg ? C.s0 : C.b;
@@ -2712,19 +2787,19 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 // rhs[0] is r_old here; the kernel leaves r = r_old - alpha q in rf->rnew, which the way up reads
                 if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
                 c->probe_begin(10);
-                LAUNCH_WIDE(wide, (k_mg_down_k<true, 3, true>), (k_mg_down_k<true, 3, true, 8>), grid, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g));
-                c->probe_end(10, 50.0);
+                LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<true, 3, true>), (k_mg_down_k<true, 3, true, 8>), (k_mg_down_k<true, 3, true, 4, true>), (k_mg_down_k<true, 3, true, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
+                c->probe_end(10, opm.cif ? 42.0 : 50.0);      // face planes: 16 B in double, 8 B in single precision
                 c->kc[KC_MG_DEFERRED_RESID] += 1;
                 rhs[0] = rf->rnew;
             } else if (l == 0) {
                 c->probe_begin(1);
                 if (KS == 3)
-                    LAUNCH_WIDE(wide, (k_mg_down_k<true, 3>), (k_mg_down_k<true, 3, false, 8>), grid, op, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
+                    LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<true, 3>), (k_mg_down_k<true, 3, false, 8>), (k_mg_down_k<true, 3, false, 4, true>), (k_mg_down_k<true, 3, false, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
                 else
                     hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
-                c->probe_end(1, c->p_diag.on ? 34.0 : 42.0);
+                c->probe_end(1, (c->p_diag.on ? 34.0 : 42.0) - (opm.cif ? 8.0 : 0.0));
             } else if (KS == 3) {
-                LAUNCH_WIDE(wide, (k_mg_down_k<false, 3>), (k_mg_down_k<false, 3, false, 8>), grid, op, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
+                LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<false, 3>), (k_mg_down_k<false, 3, false, 8>), (k_mg_down_k<false, 3, false, 4, true>), (k_mg_down_k<false, 3, false, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
             } else {
                 hipLaunchKernelGGL((k_mg_down<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], om, om2, cur[l], cg, cb);
             }
@@ -2815,7 +2890,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     for (int l = n_top - 1; l >= 0; --l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
-        const OpDev op = level_op(c, L);
+        const OpDev op = level_op(c, L), opm = level_op_mg(c, L);
         const Geo cg = coarse_view(c, l + 1);
         // coarse correction as this level sees it: its own slab rows of the replicated plane
         // (whose neighbouring rows are the halo), or the exchanged slab plane
@@ -2831,16 +2906,16 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             if (l == 0) {
                 c->probe_begin(7);
                 if (KS == 3)
-                    LAUNCH_WIDE(wide, (k_mg_up_k<true, 3>), (k_mg_up_k<true, 3, 8>), grid, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
-                                om3, oth[l], c->partials, c->nts(L.g));
+                    LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_up_k<true, 3>), (k_mg_up_k<true, 3, 8>), (k_mg_up_k<true, 3, 4, true>), (k_mg_up_k<true, 3, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
+                                om3, oth[l], c->partials, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
                 else
                     hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                        oth[l], c->partials);
-                c->probe_end(7, c->p_diag.on ? 42.0 : 50.0);
+                c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 8.0 : 0.0));
                 *dot_blocks = (int)grid.x;
             } else if (KS == 3) {
-                LAUNCH_WIDE(wide, (k_mg_up_k<false, 3>), (k_mg_up_k<false, 3, 8>), grid, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
-                            oth[l], c->partials, c->nts(L.g));
+                LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_up_k<false, 3>), (k_mg_up_k<false, 3, 8>), (k_mg_up_k<false, 3, 4, true>), (k_mg_up_k<false, 3, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
+                            oth[l], c->partials, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
             } else {
                 hipLaunchKernelGGL((k_mg_up<false>), grid, dim3(256), 0, st, op, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                    oth[l], c->partials);

@@ -425,7 +425,12 @@ def test_correction_fused_into_the_closing_flux_pass(name, tmp_path):
     sides, continuity sum and time-step minima in one marching pass) against k_correct + k_flow_bc + k_flux_march<2>:
     the same bits in every field; the continuity sum is taken over other strip widths (rounding)."""
     builder, fixup = FUSED_CORRECTION_CASES[name]
-    (f1, log1, last1), (f0, log0, last0) = _run_pair(builder, fixup, tmp_path)
+    # The turbulent half cylinder blows up in its first step, in the reference as here (nu_t ~ 1e9, dt ~ 1e-15, continuity
+    # ~ 1e6): whether the k solve of that state reaches the rounding level within its iteration budget hangs on the last
+    # bits of p, and with the single-precision multigrid faces (same solution to the tolerance, other last bits) it does not.
+    # The case is here for the symmetry rows and the curvilinear metrics of the fused kernel, so it keeps the double faces.
+    extra = {"mg_f32": 0} if name == "half_cylinder_komega_132x24" else None
+    (f1, log1, last1), (f0, log0, last0) = _run_pair(builder, fixup, tmp_path, extra)
     assert last1["kernel_counts"]["correct_flux"] > 0 and last0["kernel_counts"]["correct_flux"] == 0
     for key in f0:
         assert np.array_equal(mask_corners(f1[key]), mask_corners(f0[key])), key

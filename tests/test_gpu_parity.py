@@ -348,18 +348,30 @@ def test_fused_vcycle_matches_unfused(kind, ni, nj, sweeps, omegas):
     per_i, per_j = kind == "per_i", kind == "per_j"
     a = orc.five_point_matrix(diag, ci[:-1], ci[1:], cj[:, :-1], cj[:, 1:], per_i, per_j)
     r = rng.standard_normal((ni, nj))
+    # default (mg_f32 = 1): the multigrid levels carry face coefficients rounded to single precision (coarse levels in
+    # place, the finest level as copies read by the fused kernels only) -- a V-cycle of the rounded operator, close to,
+    # not equal to, the double-precision one; with mg_f32 = 0 fused and unfused kernels compute the same V-cycle
+    dev.set_multigrid(sweeps, sweeps, coarse_sweeps=40, fused=True, omegas=omegas)
+    z32 = dev.vcycle(r)
+    dev.set_option("mg_f32", 0)
     dev.set_multigrid(sweeps, sweeps, coarse_sweeps=40, fused=False, omegas=omegas)
     z_ref = dev.vcycle(r)
     dev.set_multigrid(sweeps, sweeps, coarse_sweeps=40, fused=True, omegas=omegas)
     z = dev.vcycle(r)
     assert rel_l2(z, z_ref) < 1e-12
+    assert 0.0 < rel_l2(z32, z_ref) < 5e-6
     x_true = rng.standard_normal((ni, nj))
     b = a.dot(x_true.ravel()).reshape(ni, nj)
-    for fused in (False, True):
+    its = {}
+    for fused, f32 in ((False, 0), (True, 0), (True, 1)):
+        dev.set_option("mg_f32", f32)
         dev.set_multigrid(sweeps, sweeps, coarse_sweeps=40, fused=fused, omegas=omegas)
         sol, iters, relres = dev.pressure_krylov(b, tol=1e-12, maxiter=300)
-        assert relres <= 1e-12 and iters < 80, (fused, iters, relres)
+        assert relres <= 1e-12 and iters < 80, (fused, f32, iters, relres)
         assert np.linalg.norm((a.dot(sol.ravel()) - b.ravel())) <= 1e-10 * np.linalg.norm(b.ravel())
+        its[(fused, f32)] = iters
+    # the Krylov operator stays double precision: same solution, and the rounded preconditioner costs no iterations
+    assert abs(its[(True, 1)] - its[(True, 0)]) <= 1, its
     dev.close()
 
 
