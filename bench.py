@@ -498,8 +498,9 @@ def main():
         # + 42 (k_mg_up) B/cell (diagonal recomputed from the face planes on every level of this all-Neumann /
         # periodic system), coarser levels (34 + 42) / 3 B/cell.  With the single-precision face planes of the fused
         # V-cycle kernels (option mg_f32, default on) each of the two passes reads 8 B per cell less.
+        # and the finest level keeps its pre-smoothed iterate in single precision (4 B less per pass).
         f32 = 0.0 if "mg_f32=0" in (args.tuning or "").replace(" ", "") else 8.0
-        pcg_bytes_per_cell_iter = 64 + 24 + (34 - f32) + (42 - f32) + ((34 - f32) + (42 - f32)) / 3.0
+        pcg_bytes_per_cell_iter = 64 + 24 + (34 - 1.5 * f32) + (42 - 1.5 * f32) + ((34 - f32) + (42 - f32)) / 3.0
         n_solves = extra_steps * args.max_iter
         press_s = phases["press"] / n_solves
         mean_p_it = float(np.mean(p_its))

@@ -182,6 +182,11 @@ __device__ __forceinline__ void store_stream(double *p, double v, int nt) {
     else *p = v;
 }
 
+__device__ __forceinline__ void store_stream_f32(float *p, float v, int nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
@@ -368,7 +373,7 @@ struct Ctx {
     size_t line_mem_bytes = 0;
     char *f32_mem = nullptr;       // single-precision face planes of the fused multigrid levels (own allocation)
     size_t f32_mem_bytes = 0;
-    int mg_v32_emul = 0;
+    int mg_v32_emul = 0;           // measurement aid: the fused V-cycle kernels round what they store (x, coarse right-hand side, correction) to single precision
     int mg_f32 = 1;                // fused V-cycle levels read their face coefficients in single precision
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
     int mg_line_dirs = 1;          // 1: a line-smoothed level sweeps both directions; 0: only those whose own coupling ratio exceeds the threshold (wall-graded 8192^2 channel: 79 iterations instead of 12, the wide centre cells need the i-lines)

@@ -1076,7 +1076,7 @@ struct ResidFuse {
     double *rnew;
 };
 
-template <bool UP, bool RF = false, bool XO = false, bool F32 = false>
+template <bool UP, bool RF = false, bool XO = false, bool F32 = false, bool XF = false>
 __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, const Geo &g, const Geo &gc, const double *b,
                                          const double *x, const double *e, int j, bool cvalid, size_t colo, size_t coloc,
                                          MgRaw &R, const double *q = nullptr) {
@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
     const int js = (mr >= 0 ? mr : NG) - NG;
     const size_t cc = (size_t)(js + NG) * P + colo;
     if (UP) {
-        R.x = x[cc];
+        R.x = XF ? (double)reinterpret_cast<const float *>(x)[cc] : x[cc];
         R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
     if (XO) R.x = x[cc];
@@ -1158,7 +1158,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
                 X[s2][2] = xn;
                 if (s2 == K) {
                     const int row = j - (K - 1);
-                    if (row >= j0 && row < j1 && out) store_stream(x + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)xn : xn, nts & 1);
+                    if (row >= j0 && row < j1 && out) {
+                        // finest level with single-precision faces: the pre-smoothed iterate, which only the post-smoothing
+                        // pass reads, is stored in single precision too (same pitch in elements, first half of the plane)
+                        if (F32 && FINE) store_stream_f32(reinterpret_cast<float *>(x) + (size_t)(row + NG) * P + colo, (float)xn, nts & 1);
+                        else store_stream(x + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)xn : xn, nts & 1);
+                    }
                 }
             }
             // residual on row j - K, summed over 2 x 2 aggregates into the coarse right-hand side
@@ -1212,10 +1217,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
             X[s2][0] = 0.0; X[s2][1] = 0.0; X[s2][2] = 0.0;
         }
         MgRaw nxt;
-        mg_fetch<true, false, false, F32>(op, df, g, gc, b, x, e, j0 - K, cvalid, colo, coloc, nxt);
+        mg_fetch<true, false, false, F32, F32 && FINE>(op, df, g, gc, b, x, e, j0 - K, cvalid, colo, coloc, nxt);
         for (int j = j0 - K; j < j1 + K; ++j) {
             const MgRaw cur = nxt;
-            if (j + 1 < j1 + K) mg_fetch<true, false, false, F32>(op, df, g, gc, b, x, e, j + 1, cvalid, colo, coloc, nxt);
+            if (j + 1 < j1 + K) mg_fetch<true, false, false, F32, F32 && FINE>(op, df, g, gc, b, x, e, j + 1, cvalid, colo, coloc, nxt);
             RC[0] = mg_row(cur, df, op, colo);
             V[0] = cur.valid;
             X[0][2] = cur.valid ? cur.x + gamma * cur.e : 0.0;              // prolongated iterate on row j
@@ -2788,7 +2793,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
                 c->probe_begin(10);
                 LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<true, 3, true>), (k_mg_down_k<true, 3, true, 8>), (k_mg_down_k<true, 3, true, 4, true>), (k_mg_down_k<true, 3, true, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
-                c->probe_end(10, opm.cif ? 42.0 : 50.0);      // face planes: 16 B in double, 8 B in single precision
+                c->probe_end(10, opm.cif ? 38.0 : 50.0);      // single precision: faces 8 B instead of 16, x 4 B instead of 8
                 c->kc[KC_MG_DEFERRED_RESID] += 1;
                 rhs[0] = rf->rnew;
             } else if (l == 0) {
@@ -2797,7 +2802,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                     LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<true, 3>), (k_mg_down_k<true, 3, false, 8>), (k_mg_down_k<true, 3, false, 4, true>), (k_mg_down_k<true, 3, false, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
                 else
                     hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
-                c->probe_end(1, (c->p_diag.on ? 34.0 : 42.0) - (opm.cif ? 8.0 : 0.0));
+                c->probe_end(1, (c->p_diag.on ? 34.0 : 42.0) - (opm.cif ? 12.0 : 0.0));
             } else if (KS == 3) {
                 LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<false, 3>), (k_mg_down_k<false, 3, false, 8>), (k_mg_down_k<false, 3, false, 4, true>), (k_mg_down_k<false, 3, false, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
             } else {
@@ -2805,7 +2810,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             }
             CFD_HIP(hipGetLastError());
             if (l < la && (L.g.cutlo || L.g.cuthi)) {
-                HaloSpec sp[2] = {{&L.g, KS, cur[l]}, {nullptr, 0, nullptr}};
+                // (a single-precision x: rows of half the bytes, which is a plane of half the pitch to the exchange)
+                Geo gx = L.g;
+                if (l == 0 && opm.cif && KS == 3) gx.pitch /= 2;
+                HaloSpec sp[2] = {{&gx, KS, cur[l]}, {nullptr, 0, nullptr}};
                 int ns = 1;
                 x_sent[l] = 1;
                 if (l + 1 < la && l + 2 < nl && level_fusable(c, l + 1, C.g, coarse_view(c, l + 2))) {
@@ -2902,7 +2910,11 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             mgeo.xcd = KS == 3 ? c->xcd_map : 0;
             const int wide = KS == 3 ? march_wide(c, mgeo, l > 0 ? WIDE_MG_COARSE : WIDE_MG_UP) : 4;
             const dim3 grid(march_grid(mgeo, wide));
-            if (!x_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, cur[l]));
+            if (!x_sent[l]) {
+                Geo gx = L.g;
+                if (l == 0 && opm.cif && KS == 3) gx.pitch /= 2;
+                CFD_TRY(halo_exchange(c, gx, KS, cur[l]));
+            }
             if (l == 0) {
                 c->probe_begin(7);
                 if (KS == 3)
@@ -2911,7 +2923,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 else
                     hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                        oth[l], c->partials);
-                c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 8.0 : 0.0));
+                c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 12.0 : 0.0));
                 *dot_blocks = (int)grid.x;
             } else if (KS == 3) {
                 LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_up_k<false, 3>), (k_mg_up_k<false, 3, 8>), (k_mg_up_k<false, 3, 4, true>), (k_mg_up_k<false, 3, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,

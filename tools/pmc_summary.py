@@ -40,11 +40,14 @@ def algo_of(k):
         return 98.7 if m.group(1) == "2" else 64
     if k.startswith("k_cg_pq<"):
         return 58
-    if k.startswith("k_mg_up_k<true, 3"):
-        return 42
-    m = re.match(r"k_mg_down_k<true, 3, (true|false)", k)
+    # fused V-cycle kernels: the last template argument says whether the face planes (-8 B) and the pre-smoothed
+    # iterate (-4 B) are single precision
+    m = re.match(r"k_mg_up_k<true, 3(?:, \d+(?:, (true|false))?)?>", k)
     if m:
-        return 50 if m.group(1) == "true" else 34
+        return 42 - (12 if m.group(1) == "true" else 0)
+    m = re.match(r"k_mg_down_k<true, 3, (true|false)(?:, \d+(?:, (true|false))?)?>", k)
+    if m:
+        return (50 if m.group(1) == "true" else 34) - (12 if m.group(2) == "true" else 0)
     m = re.match(r"k_correct_flux<(true|false), (true|false)", k)
     if m:       # correction + ghost cells + momentum right-hand sides: 17 planes read, 5 written (+ k, + lmin)
         return 176 + (8 if m.group(1) == "true" else 0) + (8 if (m.group(2) == "true" and m.group(1) != "true") else 0)
