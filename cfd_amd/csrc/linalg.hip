@@ -136,6 +136,15 @@ __device__ __forceinline__ double offdiag(const OpDev &op, F xf, size_t c, int i
     return s;
 }
 
+// Offset of the row above for the north-face load, zero on the last memory row of a plane.  Opaque to the optimiser:
+// written as a plain conditional the compiler turns `cj[c + (last ? 0 : P)]` into `last ? cs : cj[c + P]`, a move of
+// the value the c_s load has just been issued for, and the wave then waits for the row it is prefetching.
+__device__ __forceinline__ size_t north_offset(bool not_last, size_t P) {
+    size_t off = not_last ? P : 0;
+    asm volatile("" : "+s"(off));
+    return off;
+}
+
 template <int NB>
 struct Vecs {
     double *p[NB];
@@ -887,7 +896,7 @@ __global__ __launch_bounds__(256) void k_mg_down(OpDev op, MarchGeo mg, DiagFix 
             R.row = (mr >= 0 ? mr : NG) - NG;
             const size_t cc = (size_t)(mr >= 0 ? mr : NG) * P + colo;
             R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
-            R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
+            R.cn = op.cj[cc + north_offset(mr < g.nj + 2 * NG - 1, P)];
             // the outermost halo row of a high slab cut has no north face in memory: its D is read
             R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
             if (!df.on || mr == g.nj + 2 * NG - 1) R.row = -1000000;
@@ -983,7 +992,7 @@ __global__ __launch_bounds__(256) void k_mg_up(OpDev op, MarchGeo mg, DiagFix df
             R.x = x[cc];
             R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
             R.b = b[cc]; R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
-            R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
+            R.cn = op.cj[cc + north_offset(mr < g.nj + 2 * NG - 1, P)];
             R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
             R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
         };
@@ -1061,8 +1070,11 @@ struct SweepOm {
     double w[K];
 };
 
+// what a row fetch brings in, as loaded: conversions and arithmetic wait until the row is consumed, one trip later
+// (anything computed from a value in the fetch itself makes the wave wait for the loads it has just issued)
 struct MgRaw {
     double b, d, cw, ce, cs, cn, x, e, q;
+    float fw, fe, fs, fn, fx;          // single-precision faces / iterate (F32 / XF forms)
     int row;
     bool valid;
 };
@@ -1086,24 +1098,27 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
     const int js = (mr >= 0 ? mr : NG) - NG;
     const size_t cc = (size_t)(js + NG) * P + colo;
     if (UP) {
-        R.x = XF ? (double)reinterpret_cast<const float *>(x)[cc] : x[cc];
+        if (XF) R.fx = reinterpret_cast<const float *>(x)[cc];
+        else R.x = x[cc];
         R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
     if (XO) R.x = x[cc];
     R.b = b[cc];
     if (RF) R.q = q[cc];
-    const size_t cn_at = cc + (mr < g.nj + 2 * NG - 1 ? P : 0);
+    const size_t cn_at = cc + north_offset(mr < g.nj + 2 * NG - 1, P);
     if (F32) {
-        R.cw = op.cif[cc]; R.ce = op.cif[cc + 1]; R.cs = op.cjf[cc]; R.cn = op.cjf[cn_at];
+        R.fw = op.cif[cc]; R.fe = op.cif[cc + 1]; R.fs = op.cjf[cc]; R.fn = op.cjf[cn_at];
     } else {
         R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc]; R.cn = op.cj[cn_at];
     }
     R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
     R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
 }
+template <bool F32 = false>
 __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const OpDev &op, size_t colo) {
-    const double d = R.row > -1000000 ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - CO, R.row, df, op) : R.d;
-    return RowC{R.b, d, fast_rcp(d), R.cw, R.ce, R.cs, R.cn};
+    const double cw = F32 ? (double)R.fw : R.cw, ce = F32 ? (double)R.fe : R.ce, cs = F32 ? (double)R.fs : R.cs, cn = F32 ? (double)R.fn : R.cn;
+    const double d = R.row > -1000000 ? diag_from_faces(cw, ce, cs, cn, (int)colo - CO, R.row, df, op) : R.d;
+    return RowC{R.b, d, fast_rcp(d), cw, ce, cs, cn};
 }
 
 template <bool FINE, int K, bool RF = false, int WPB = 4, bool F32 = false>
@@ -1148,7 +1163,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
                 const bool own = (j >= j0 && j < j1) || (g.cutlo && j < 0 && j0 == 0) || (g.cuthi && j >= g.nj && j1 == g.nj);
                 if (own && out) store_stream(rf.rnew + (size_t)(j + NG) * P + colo, cur.b, nts & 1);
             }
-            RC[0] = mg_row(cur, df, op, colo);
+            RC[0] = mg_row<F32>(cur, df, op, colo);
             V[0] = cur.valid;
             X[1][2] = V[0] ? om.w[0] * RC[0].b * RC[0].inv : 0.0;          // first sweep from a zero guess
 #pragma unroll
@@ -1221,9 +1236,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
         for (int j = j0 - K; j < j1 + K; ++j) {
             const MgRaw cur = nxt;
             if (j + 1 < j1 + K) mg_fetch<true, false, false, F32, F32 && FINE>(op, df, g, gc, b, x, e, j + 1, cvalid, colo, coloc, nxt);
-            RC[0] = mg_row(cur, df, op, colo);
+            RC[0] = mg_row<F32>(cur, df, op, colo);
             V[0] = cur.valid;
-            X[0][2] = cur.valid ? cur.x + gamma * cur.e : 0.0;              // prolongated iterate on row j
+            X[0][2] = cur.valid ? ((F32 && FINE) ? (double)cur.fx : cur.x) + gamma * cur.e : 0.0;   // prolongated iterate on row j
 #pragma unroll
             for (int s2 = 1; s2 <= K; ++s2) {                               // sweep s2 on row j - s2
                 double v = jac(X[s2 - 1][1], X[s2 - 1][0], X[s2 - 1][2], RC[s2], om.w[s2 - 1]);
@@ -1730,7 +1745,7 @@ __global__ __launch_bounds__(256) void k_cheb2(OpDev op, MarchGeo mg, double c1a
             const int mr = mem_row(j, g, op.per_j);
             valid = cvalid && mr >= 0;
             const size_t c = (size_t)(mr >= 0 ? mr : NG) * P + colo;
-            a.d = op.D[c]; a.cw = op.ci[c]; a.ce = op.ci[c + 1]; a.cs = op.cj[c]; a.cn = op.cj[c + (mr < g.nj + 2 * NG - 1 ? P : 0)];
+            a.d = op.D[c]; a.cw = op.ci[c]; a.ce = op.ci[c + 1]; a.cs = op.cj[c]; a.cn = op.cj[c + north_offset(mr < g.nj + 2 * NG - 1, P)];
             a.inv = fast_rcp(a.d);
 #pragma unroll
             for (int q = 0; q < NB; ++q) xv[q] = valid ? xk.p[q][c] : 0.0;
@@ -3044,13 +3059,17 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 // WPB x 512 contiguous bytes of each plane row at a time -- the strips' 64-lane windows are not aligned to the
 // 128-byte lines (62 output columns per strip), and waves drifting apart made every one of them pay for its two
 // partial lines (tools/stream_probe3.hip: 4.1 TB/s for misaligned independent waves, 4.8 - 4.9 in lockstep).
-template <int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen, int first, int xzero,
+// FIRST / XZERO (first / second step of a solve: no p_old / no x to read) are template arguments and the diagonal is
+// formed where a row is consumed: a wave-uniform branch around a load, or arithmetic on a row's coefficients right
+// after its loads were issued, makes the wave wait for the row it has just asked for (the prefetch then hides nothing).
+template <int WPB, bool FIRST, bool XZERO>
+__global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen,
                                                     const double *z, const double *pold, double *pnew, double *q, double *x, double *partials,
                                                     int nts) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const size_t P = g.pitch;
+    constexpr bool first = FIRST, xzero = XZERO;
     const double beta = first ? 0.0 : safe_div(s->rz[gen], s->rz[gen ^ 1]);
     const double alpha_prev = first ? 0.0 : safe_div(s->rz[gen ^ 1], s->pq);
     double dot = 0.0;
@@ -3077,6 +3096,7 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
         struct RowIn {
             double z, po, d, cw, ce, cs, cn, xv;
             bool valid;
+            int row;
             size_t cell;
         };
         auto fetch = [&](int j, RowIn &R) {
@@ -3088,9 +3108,10 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
             R.z = z[cc];
             R.xv = (first || xzero) ? 0.0 : x[cc];      // xzero: x = 0 was never stored (second iteration)
             R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
-            R.cn = op.cj[cc + (mr < g.nj + 2 * NG - 1 ? P : 0)];
+            R.cn = op.cj[cc + north_offset(mr < g.nj + 2 * NG - 1, P)];
             // rows j0-1 .. j1 only: the outermost halo row is never touched here
-            R.d = df.on ? diag_from_faces(R.cw, R.ce, R.cs, R.cn, (int)colo - CO, (mr >= 0 ? mr : NG) - NG, df, op) : op.D[cc];
+            R.row = (mr >= 0 ? mr : NG) - NG;
+            R.d = df.on ? 0.0 : op.D[cc];
         };
         RowIn nxt;
         fetch(j0 - 1, nxt);
@@ -3103,7 +3124,8 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
             po_c = cur.po;
             xv_c = cur.xv;
             pc = valid ? cur.z + beta * po_c : 0.0;
-            const double d_c = cur.d, cw_c = cur.cw, ce_c = cur.ce, cs_c = cur.cs, cn_c = cur.cn;
+            const double cw_c = cur.cw, ce_c = cur.ce, cs_c = cur.cs, cn_c = cur.cn;
+            const double d_c = df.on ? diag_from_faces(cw_c, ce_c, cs_c, cn_c, (int)colo - CO, cur.row, df, op) : cur.d;
             // row j-1
             const double pl = lane_left(pb), pr = lane_right(pb);
             if (j - 1 >= j0 && out) {
@@ -3274,12 +3296,19 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             p = pbuf[gen];
             CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
             c->probe_begin(0);
-            if (wide == 8)
-                hipLaunchKernelGGL((k_cg_pq<8>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, it == 1, z, pold, p, q, x,
-                                   c->partials, c->nts(g));
-            else
-                hipLaunchKernelGGL((k_cg_pq<4>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, it == 0, it == 1, z, pold, p, q, x,
-                                   c->partials, c->nts(g));
+#define LAUNCH_CG_PQ(FIRST, XZERO)                                                                                            \
+    do {                                                                                                                      \
+        if (wide == 8)                                                                                                        \
+            hipLaunchKernelGGL((k_cg_pq<8, FIRST, XZERO>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
+                               c->partials, c->nts(g));                                                                       \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_cg_pq<4, FIRST, XZERO>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
+                               c->partials, c->nts(g));                                                                       \
+    } while (0)
+            if (it == 0) LAUNCH_CG_PQ(true, false);
+            else if (it == 1) LAUNCH_CG_PQ(false, true);
+            else LAUNCH_CG_PQ(false, false);
+#undef LAUNCH_CG_PQ
             // algorithmic bytes: z, c_i, c_j read, p', q written (40); + p_old from the second step (48 -> with the x store 56);
             // + the x read from the third (64)
             c->probe_end(0, it == 0 ? 40.0 : (it == 1 ? 56.0 : 64.0));
