@@ -500,7 +500,8 @@ def main():
         # V-cycle kernels (option mg_f32, default on) each of the two passes reads 8 B per cell less.
         # and the finest level keeps its pre-smoothed iterate in single precision (4 B less per pass).
         f32 = 0.0 if "mg_f32=0" in (args.tuning or "").replace(" ", "") else 8.0
-        pcg_bytes_per_cell_iter = 64 + 24 + (34 - 1.5 * f32) + (42 - 1.5 * f32) + ((34 - f32) + (42 - f32)) / 3.0
+        # ... and hands z to the direction step in single precision (4 B less in each of the two kernels)
+        pcg_bytes_per_cell_iter = (64 - 0.5 * f32) + 24 + (34 - 1.5 * f32) + (42 - 2.0 * f32) + ((34 - f32) + (42 - f32)) / 3.0
         n_solves = extra_steps * args.max_iter
         press_s = phases["press"] / n_solves
         mean_p_it = float(np.mean(p_its))

@@ -829,20 +829,26 @@ __device__ __forceinline__ RowC load_rowc(const OpDev &op, const double *b, size
 // the recomputed diagonal has the bits of the stored one).
 __device__ __forceinline__ double diag_from_faces(double cw, double ce, double cs, double cn, int col, int row,
                                                   const DiagFix &f, const OpDev &op) {
+    // the sum first, the rows next to a detached reference cell again with their fix-ups: written the other way round
+    // (fix the faces up, then sum) every row pays four register copies where the two paths join
+    double d = ((cw + ce) + cs) + cn;
     if (f.pi >= 0) {
         int di = col - f.pi, dj = row - f.pj;
         if (op.per_i) { if (di == op.g.ni - 1) di = -1; else if (di == 1 - op.g.ni) di = 1; }
         if (op.per_j) { if (dj == op.g.nj - 1) dj = -1; else if (dj == 1 - op.g.nj) dj = 1; }
-        if (dj == 0) {
-            if (di == 0) { cw += f.oW; ce += f.oE; cs += f.oS; cn += f.oN; }
-            else if (di == -1) ce += f.cW;
-            else if (di == 1) cw += f.cE;
-        } else if (di == 0) {
-            if (dj == -1) cn += f.cS;
-            else if (dj == 1) cs += f.cN;
+        if (dj >= -1 && dj <= 1) {           // wave-uniform
+            if (dj == 0) {
+                if (di == 0) { cw += f.oW; ce += f.oE; cs += f.oS; cn += f.oN; }
+                else if (di == -1) ce += f.cW;
+                else if (di == 1) cw += f.cE;
+            } else if (di == 0) {
+                if (dj == -1) cn += f.cS;
+                else if (dj == 1) cs += f.cN;
+            }
+            d = ((cw + ce) + cs) + cn;
         }
     }
-    return ((cw + ce) + cs) + cn;
+    return d;
 }
 
 __device__ __forceinline__ double jac(double xc, double xs, double xn, const RowC &r, double omega) {
@@ -1201,7 +1207,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
     }
 }
 
-template <bool FINE, int K, int WPB = 4, bool F32 = false>
+// ZF (finest level, PCG): the result z goes out in single precision -- k_cg_pq reads it as such -- and (r, z) is taken
+// with the rounded value, the z the direction step will see.
+template <bool FINE, int K, int WPB = 4, bool F32 = false, bool ZF = false>
 __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
                                                       const double *e, double gamma, SweepOm<K> om, double *xn, double *partials, int nts = 0) {
     const Geo g = op.g;
@@ -1247,8 +1255,14 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
                 if (s2 == K) {
                     const int row = j - K;
                     if (row >= j0 && row < j1 && out) {
-                        store_stream(xn + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)v : v, nts & 1);
-                        if (FINE) dot += RC[K].b * v;
+                        if (ZF) {
+                            const float vf = (float)v;
+                            store_stream_f32(reinterpret_cast<float *>(xn) + (size_t)(row + NG) * P + colo, vf, nts & 1);
+                            dot += RC[K].b * (double)vf;
+                        } else {
+                            store_stream(xn + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)v : v, nts & 1);
+                            if (FINE) dot += RC[K].b * v;
+                        }
                     }
                 }
             }
@@ -2760,7 +2774,8 @@ static inline MarchGeo march_geo_w(const Geo &g, int W) {
 // One V-cycle: z ~= A^-1 r starting from zero.  The result lands in *zout, which is
 // either z0 or z1 (Jacobi ping-pong).
 static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks,
-                       const ResidFuse *rf = nullptr) {
+                       const ResidFuse *rf = nullptr, bool *z_f32 = nullptr) {
+    if (z_f32) *z_f32 = false;
     hipStream_t st = c->stream;
     const int nl = (int)c->levels.size();
     // sweep s of a smoothing pass uses omega (even s) or omega2 (odd s): with omega2 != omega the two
@@ -2932,13 +2947,18 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             }
             if (l == 0) {
                 c->probe_begin(7);
-                if (KS == 3)
+                if (KS == 3 && opm.cif && z_f32) {
+                    // the caller (fused PCG) takes z in single precision
+                    LAUNCH_WIDE(wide, (k_mg_up_k<true, 3, 4, true, true>), (k_mg_up_k<true, 3, 8, true, true>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e,
+                                c->mg_gamma, om3, oth[l], c->partials, c->nts(L.g));
+                    *z_f32 = true;
+                } else if (KS == 3)
                     LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_up_k<true, 3>), (k_mg_up_k<true, 3, 8>), (k_mg_up_k<true, 3, 4, true>), (k_mg_up_k<true, 3, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
                                 om3, oth[l], c->partials, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
                 else
                     hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                        oth[l], c->partials);
-                c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 12.0 : 0.0));
+                c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 12.0 : 0.0) - ((z_f32 && *z_f32) ? 4.0 : 0.0));
                 *dot_blocks = (int)grid.x;
             } else if (KS == 3) {
                 LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_up_k<false, 3>), (k_mg_up_k<false, 3, 8>), (k_mg_up_k<false, 3, 4, true>), (k_mg_up_k<false, 3, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
@@ -3062,7 +3082,7 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 // FIRST / XZERO (first / second step of a solve: no p_old / no x to read) are template arguments and the diagonal is
 // formed where a row is consumed: a wave-uniform branch around a load, or arithmetic on a row's coefficients right
 // after its loads were issued, makes the wave wait for the row it has just asked for (the prefetch then hides nothing).
-template <int WPB, bool FIRST, bool XZERO>
+template <int WPB, bool FIRST, bool XZERO, bool ZF = false>
 __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen,
                                                     const double *z, const double *pold, double *pnew, double *q, double *x, double *partials,
                                                     int nts) {
@@ -3095,6 +3115,7 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
         // software pipeline: row j + 1 is loaded while row j is processed
         struct RowIn {
             double z, po, d, cw, ce, cs, cn, xv;
+            float zf;                  // ZF: z as the finest-level post-smoother stored it (converted where consumed)
             bool valid;
             int row;
             size_t cell;
@@ -3105,7 +3126,8 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
             const size_t cc = (size_t)(mr >= 0 ? mr : NG) * P + colo;
             R.cell = cc;
             R.po = first ? 0.0 : pold[cc];
-            R.z = z[cc];
+            if (ZF) R.zf = reinterpret_cast<const float *>(z)[cc];
+            else R.z = z[cc];
             R.xv = (first || xzero) ? 0.0 : x[cc];      // xzero: x = 0 was never stored (second iteration)
             R.cw = op.ci[cc]; R.ce = op.ci[cc + 1]; R.cs = op.cj[cc];
             R.cn = op.cj[cc + north_offset(mr < g.nj + 2 * NG - 1, P)];
@@ -3123,7 +3145,7 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
             const size_t cc = cur.cell;
             po_c = cur.po;
             xv_c = cur.xv;
-            pc = valid ? cur.z + beta * po_c : 0.0;
+            pc = valid ? (ZF ? (double)cur.zf : cur.z) + beta * po_c : 0.0;
             const double cw_c = cur.cw, ce_c = cur.ce, cs_c = cur.cs, cn_c = cur.cn;
             const double d_c = df.on ? diag_from_faces(cw_c, ce_c, cs_c, cn_c, (int)colo - CO, cur.row, df, op) : cur.d;
             // row j-1
@@ -3275,13 +3297,14 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         const int gen = it & 1;
         double *z = nullptr;
         int db = 0;
+        bool zf = false;           // z came out of the V-cycle in single precision (finest level with single-precision faces)
         if (deferred) {
             const ResidFuse rf{q, &S->rz[deferred_gen], &S->pq, r_other};
-            CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db, &rf));
+            CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db, &rf, fused ? &zf : nullptr));
             std::swap(r, r_other);
             deferred = false;
         } else {
-            CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db));
+            CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db, nullptr, fused ? &zf : nullptr));
         }
         if (db > 0) {
             CFD_TRY(finish_to(c, db, 1, CG_OFF_OF(rz[gen])));     // (r, z) came out of the fused up-sweep
@@ -3294,24 +3317,37 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         if (fused) {
             double *pold = pbuf[gen ^ 1];
             p = pbuf[gen];
-            CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
+            if (zf && (g.cutlo || g.cuthi) && c->comm.nranks > 1) {
+                Geo gz = g;
+                gz.pitch /= 2;                     // rows of half the bytes
+                HaloSpec sp[2] = {{&gz, 1, z}, {&g, 1, pold}};
+                CFD_TRY(halo_exchange_multi(c, it == 0 ? 1 : 2, sp));
+            } else {
+                CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
+            }
             c->probe_begin(0);
-#define LAUNCH_CG_PQ(FIRST, XZERO)                                                                                            \
+#define LAUNCH_CG_PQ(FIRST, XZERO, ZF)                                                                                        \
     do {                                                                                                                      \
         if (wide == 8)                                                                                                        \
-            hipLaunchKernelGGL((k_cg_pq<8, FIRST, XZERO>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
+            hipLaunchKernelGGL((k_cg_pq<8, FIRST, XZERO, ZF>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
                                c->partials, c->nts(g));                                                                       \
         else                                                                                                                  \
-            hipLaunchKernelGGL((k_cg_pq<4, FIRST, XZERO>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
+            hipLaunchKernelGGL((k_cg_pq<4, FIRST, XZERO, ZF>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
                                c->partials, c->nts(g));                                                                       \
     } while (0)
-            if (it == 0) LAUNCH_CG_PQ(true, false);
-            else if (it == 1) LAUNCH_CG_PQ(false, true);
-            else LAUNCH_CG_PQ(false, false);
+            if (zf) {
+                if (it == 0) LAUNCH_CG_PQ(true, false, true);
+                else if (it == 1) LAUNCH_CG_PQ(false, true, true);
+                else LAUNCH_CG_PQ(false, false, true);
+            } else {
+                if (it == 0) LAUNCH_CG_PQ(true, false, false);
+                else if (it == 1) LAUNCH_CG_PQ(false, true, false);
+                else LAUNCH_CG_PQ(false, false, false);
+            }
 #undef LAUNCH_CG_PQ
             // algorithmic bytes: z, c_i, c_j read, p', q written (40); + p_old from the second step (48 -> with the x store 56);
             // + the x read from the third (64)
-            c->probe_end(0, it == 0 ? 40.0 : (it == 1 ? 56.0 : 64.0));
+            c->probe_end(0, (it == 0 ? 40.0 : (it == 1 ? 56.0 : 64.0)) - (zf ? 4.0 : 0.0));
             c->kc[KC_CG_PQ] += 1;
             CFD_HIP(hipGetLastError());
             CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));

@@ -38,13 +38,16 @@ def algo_of(k):
     m = re.match(r"k_chebk<(\d), 4", k)
     if m:
         return 98.7 if m.group(1) == "2" else 64
+    m = re.match(r"k_cg_pq<\d+, (true|false), (true|false)(?:, (true|false))?>", k)
+    if m:       # first / second / later direction step of a solve; z in single precision
+        return (40 if m.group(1) == "true" else (56 if m.group(2) == "true" else 64)) - (4 if m.group(3) == "true" else 0)
     if k.startswith("k_cg_pq<"):
         return 58
     # fused V-cycle kernels: the last template argument says whether the face planes (-8 B) and the pre-smoothed
     # iterate (-4 B) are single precision
-    m = re.match(r"k_mg_up_k<true, 3(?:, \d+(?:, (true|false))?)?>", k)
-    if m:
-        return 42 - (12 if m.group(1) == "true" else 0)
+    m = re.match(r"k_mg_up_k<true, 3(?:, \d+(?:, (true|false)(?:, (true|false))?)?)?>", k)
+    if m:       # ..., single-precision faces and x, single-precision z
+        return 42 - (12 if m.group(1) == "true" else 0) - (4 if m.group(2) == "true" else 0)
     m = re.match(r"k_mg_down_k<true, 3, (true|false)(?:, \d+(?:, (true|false))?)?>", k)
     if m:
         return (50 if m.group(1) == "true" else 34) - (12 if m.group(2) == "true" else 0)
