@@ -1128,7 +1128,7 @@ __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const 
 }
 
 template <bool FINE, int K, bool RF = false, int WPB = 4, bool F32 = false>
-__global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
                                                         Geo gc, double *bc, ResidFuse rf = ResidFuse{}, int nts = 0) {
     const Geo g = op.g;
     const double alpha = RF ? safe_div(rf.rz[0], rf.pq[0]) : 0.0;
@@ -1157,11 +1157,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
             X[s2][0] = 0.0; X[s2][1] = 0.0; X[s2][2] = 0.0;
         }
         double rsum = 0.0;
-        MgRaw nxt;
-        mg_fetch<false, RF, false, F32>(op, df, g, gc, b, nullptr, nullptr, j0 - K, cvalid, colo, 0, nxt, rf.q);
-        for (int j = j0 - K; j < j1 + K; ++j) {
-            MgRaw cur = nxt;
-            if (j + 1 < j1 + K) mg_fetch<false, RF, false, F32>(op, df, g, gc, b, nullptr, nullptr, j + 1, cvalid, colo, 0, nxt, rf.q);
+        // two rows of loads in flight per wave (see k_mg_up_k)
+        const int jend = j1 + K;
+        auto fetch = [&](int j, MgRaw &R) {
+            mg_fetch<false, RF, false, F32>(op, df, g, gc, b, nullptr, nullptr, j < jend ? j : jend - 1, cvalid, colo, 0, R, rf.q);
+        };
+        auto trip = [&](int j, MgRaw cur) {
             if (RF) {
                 cur.b = cur.b - alpha * cur.q;                               // k_cg_r's expression
                 // own rows, and at a slab cut the ghost rows next to the first / last segment (formed from the neighbour's
@@ -1202,6 +1203,21 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
             for (int s2 = K; s2 >= 1; --s2) { RC[s2] = RC[s2 - 1]; V[s2] = V[s2 - 1]; }
 #pragma unroll
             for (int s2 = 1; s2 <= K; ++s2) { X[s2][0] = X[s2][1]; X[s2][1] = X[s2][2]; }
+        };
+        MgRaw r0, r1;
+        fetch(j0 - K, r0);
+        fetch(j0 - K + 1, r1);
+        for (int j = j0 - K; j < jend; j += 2) {
+            {
+                const MgRaw cur = r0;
+                fetch(j + 2, r0);
+                trip(j, cur);
+            }
+            if (j + 1 < jend) {
+                const MgRaw cur = r1;
+                fetch(j + 3, r1);
+                trip(j + 1, cur);
+            }
             if (WPB > 4) __syncthreads();       // lockstep: same segment, same trip count for every wave of the workgroup
         }
     }
@@ -1210,7 +1226,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_down_k(OpDev op, MarchGeo mg, D
 // ZF (finest level, PCG): the result z goes out in single precision -- k_cg_pq reads it as such -- and (r, z) is taken
 // with the rounded value, the z the direction step will see.
 template <bool FINE, int K, int WPB = 4, bool F32 = false, bool ZF = false>
-__global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
                                                       const double *e, double gamma, SweepOm<K> om, double *xn, double *partials, int nts = 0) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
@@ -1239,11 +1255,13 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
             V[s2] = false;
             X[s2][0] = 0.0; X[s2][1] = 0.0; X[s2][2] = 0.0;
         }
-        MgRaw nxt;
-        mg_fetch<true, false, false, F32, F32 && FINE>(op, df, g, gc, b, x, e, j0 - K, cvalid, colo, coloc, nxt);
-        for (int j = j0 - K; j < j1 + K; ++j) {
-            const MgRaw cur = nxt;
-            if (j + 1 < j1 + K) mg_fetch<true, false, false, F32, F32 && FINE>(op, df, g, gc, b, x, e, j + 1, cvalid, colo, coloc, nxt);
+        // two rows of loads in flight per wave (as in k_chebk): rows j + 2 and j + 3 are asked for while rows j and j + 1 are
+        // worked on; a fetch beyond the last row repeats it and is never consumed (no branch around the loads)
+        const int jend = j1 + K;
+        auto fetch = [&](int j, MgRaw &R) {
+            mg_fetch<true, false, false, F32, F32 && FINE>(op, df, g, gc, b, x, e, j < jend ? j : jend - 1, cvalid, colo, coloc, R);
+        };
+        auto trip = [&](int j, const MgRaw &cur) {
             RC[0] = mg_row<F32>(cur, df, op, colo);
             V[0] = cur.valid;
             X[0][2] = cur.valid ? ((F32 && FINE) ? (double)cur.fx : cur.x) + gamma * cur.e : 0.0;   // prolongated iterate on row j
@@ -1270,7 +1288,22 @@ __global__ __launch_bounds__(64 * WPB) void k_mg_up_k(OpDev op, MarchGeo mg, Dia
             for (int s2 = K; s2 >= 1; --s2) { RC[s2] = RC[s2 - 1]; V[s2] = V[s2 - 1]; }
 #pragma unroll
             for (int s2 = 0; s2 <= K; ++s2) { X[s2][0] = X[s2][1]; X[s2][1] = X[s2][2]; }
-            if (WPB > 4) __syncthreads();       // lockstep
+        };
+        MgRaw r0, r1;
+        fetch(j0 - K, r0);
+        fetch(j0 - K + 1, r1);
+        for (int j = j0 - K; j < jend; j += 2) {
+            {
+                const MgRaw cur = r0;
+                fetch(j + 2, r0);
+                trip(j, cur);
+            }
+            if (j + 1 < jend) {
+                const MgRaw cur = r1;
+                fetch(j + 3, r1);
+                trip(j + 1, cur);
+            }
+            if (WPB > 4) __syncthreads();       // lockstep: one barrier per two rows
         }
     }
     if (FINE) {
