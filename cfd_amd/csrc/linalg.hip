@@ -3168,12 +3168,8 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
             R.row = (mr >= 0 ? mr : NG) - NG;
             R.d = df.on ? 0.0 : op.D[cc];
         };
-        RowIn nxt;
-        fetch(j0 - 1, nxt);
         double xv_b = 0.0, xv_c;
-        for (int j = j0 - 1; j <= j1; ++j) {
-            const RowIn cur = nxt;
-            if (j < j1) fetch(j + 1, nxt);
+        auto trip = [&](int j, const RowIn &cur) {
             const bool valid = cur.valid;
             const size_t cc = cur.cell;
             po_c = cur.po;
@@ -3193,6 +3189,22 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
             pa = pb; pb = pc; po_b = po_c; xv_b = xv_c;
             d_b = d_c; cw_b = cw_c; ce_b = ce_c; cs_b = cs_c; cn_b = cn_c;
             cell_b = cc;
+        };
+        // two rows of loads in flight per wave; a fetch beyond the last row repeats it and is never consumed
+        RowIn r0, r1;
+        fetch(j0 - 1, r0);
+        fetch(min(j0, j1), r1);
+        for (int j = j0 - 1; j <= j1; j += 2) {
+            {
+                const RowIn cur = r0;
+                fetch(min(j + 2, j1), r0);
+                trip(j, cur);
+            }
+            if (j + 1 <= j1) {
+                const RowIn cur = r1;
+                fetch(min(j + 3, j1), r1);
+                trip(j + 1, cur);
+            }
             if (LOCK) __syncthreads();       // same j0, j1 for every wave of the workgroup: uniform trip count
         }
     }
