@@ -1688,6 +1688,10 @@ static inline MarchGeo march_geo_k(const Geo &g, int K) {
     m.nstrips = (g.ni + (64 - 2 * K) - 1) / (64 - 2 * K);
     int Ls = 64;
     while (Ls > 8 && (long)m.nstrips * ((g.nj + Ls - 1) / Ls) < 8192) Ls /= 2;
+    // levels too small to fill the GPU even then are chains of dependent row trips (Ls + 2K of them per launch):
+    // shorter segments shorten the chain, the redundant halo rows cost nothing there
+    // (8192^2: 43.35 -> 43.15 ms per step from the 1024^2 ... 128^2 levels; 1024^2: see DESIGN section 5)
+    while (Ls > 2 && (long)m.nstrips * ((g.nj + Ls - 1) / Ls) < 2048) Ls /= 2;
     m.Ls = Ls;
     m.nsegs = (g.nj + Ls - 1) / Ls;
     return m;
