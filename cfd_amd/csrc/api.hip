@@ -632,6 +632,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "mg_tail") { c->mg_tail = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line") { c->mg_line = iv < 0 ? -1 : (iv ? 1 : 0); c->p_built = false; }
     else if (n == "mg_v32_emul") c->mg_v32_emul = iv ? 1 : 0;
+    else if (n == "rr_byproduct") c->rr_byproduct = iv ? 1 : 0;
     else if (n == "mg_f32") { c->mg_f32 = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_dirs") { c->mg_line_dirs = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }

@@ -373,6 +373,7 @@ struct Ctx {
     size_t line_mem_bytes = 0;
     char *f32_mem = nullptr;       // single-precision face planes of the fused multigrid levels (own allocation)
     size_t f32_mem_bytes = 0;
+    int rr_byproduct = 1;          // (r, r) of the iteration before the expected last one from the next pre-smoother
     int mg_v32_emul = 0;           // measurement aid: the fused V-cycle kernels round what they store (x, coarse right-hand side, correction) to single precision
     int mg_f32 = 1;                // fused V-cycle levels read their face coefficients in single precision
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)

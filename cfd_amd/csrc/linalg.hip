@@ -1092,6 +1092,8 @@ struct ResidFuse {
     const double *q;
     const double *rz, *pq;       // alpha = rz / pq (CgScal of the running solve)
     double *rnew;
+    double *rr_partials = nullptr;     // non-null: |r|^2 of the rows a block owns, one partial sum per block
+    int rr_slot = 0;                   // ... and the Ctx::scal slot their sum goes to (host side)
 };
 
 template <bool UP, bool RF = false, bool XO = false, bool F32 = false, bool XF = false>
@@ -1135,6 +1137,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const size_t P = g.pitch;
     constexpr int W = 64 - 2 * K;
+    double rr2 = 0.0;
     const MarchItems<WPB> items(mg.nstrips, mg.nsegs, mg.xcd, wave);
     for (int item = items.first; item < items.count; item += items.stride) {
         int strip, seg;
@@ -1169,6 +1172,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 // r_old and q rows, they are the neighbour's r): the way up reads them
                 const bool own = (j >= j0 && j < j1) || (g.cutlo && j < 0 && j0 == 0) || (g.cuthi && j >= g.nj && j1 == g.nj);
                 if (own && out) store_stream(rf.rnew + (size_t)(j + NG) * P + colo, cur.b, nts & 1);
+                if (j >= j0 && j < j1 && out) rr2 += cur.b * cur.b;            // (r, r) of this slab's own cells
             }
             RC[0] = mg_row<F32>(cur, df, op, colo);
             V[0] = cur.valid;
@@ -1219,6 +1223,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 trip(j + 1, cur);
             }
             if (WPB > 4) __syncthreads();       // lockstep: same segment, same trip count for every wave of the workgroup
+        }
+    }
+    if (RF) {
+        if (rf.rr_partials) {            // kernel argument: every wave of the grid takes the same way
+            __shared__ double sm[WPB];
+            const double w = wsum(rr2);
+            if (lane == 0) sm[wave] = w;
+            __syncthreads();
+            if (threadIdx.x == 0) rf.rr_partials[blockIdx.x] = sum_waves<WPB>(sm);
         }
     }
 }
@@ -2863,6 +2876,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 c->probe_end(10, opm.cif ? 38.0 : 50.0);      // single precision: faces 8 B instead of 16, x 4 B instead of 8
                 c->kc[KC_MG_DEFERRED_RESID] += 1;
                 rhs[0] = rf->rnew;
+                if (rf->rr_partials) {
+                    CFD_HIP(hipGetLastError());
+                    CFD_TRY(sum_finish(c, rf->rr_partials, (int)grid.x, 1, c->scal + rf->rr_slot));
+                }
             } else if (l == 0) {
                 c->probe_begin(1);
                 if (KS == 3)
@@ -3341,14 +3358,15 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
                            level_fusable(c, 0, L0.g, coarse_view(c, 1));
     double *r_other = c->kry[1];
     bool deferred = false;
-    int deferred_gen = 0;
+    int deferred_gen = 0, deferred_rr_slot = 0;
     while (it < maxiter) {
         const int gen = it & 1;
         double *z = nullptr;
         int db = 0;
         bool zf = false;           // z came out of the V-cycle in single precision (finest level with single-precision faces)
         if (deferred) {
-            const ResidFuse rf{q, &S->rz[deferred_gen], &S->pq, r_other};
+            ResidFuse rf{q, &S->rz[deferred_gen], &S->pq, r_other};
+            if (deferred_rr_slot) { rf.rr_partials = c->partials + (size_t)7 * MAX_PARTIALS; rf.rr_slot = deferred_rr_slot; }
             CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db, &rf, fused ? &zf : nullptr));
             std::swap(r, r_other);
             deferred = false;
@@ -3404,6 +3422,16 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             if (can_defer && it + (c->host_lag ? 2 : 3) < c->p_iters_hint && it + 1 < maxiter) {
                 deferred = true;               // the next V-cycle forms r itself; nobody reads |r| of this iteration
                 deferred_gen = gen;
+                deferred_rr_slot = 0;
+                ++it;
+                continue;
+            }
+            // the iteration before the expected last one: its |r|^2 is only read together with the last one's, so the
+            // next V-cycle's pre-smoother forms r AND sums (r, r) into the history slot (no k_cg_r pass: 24 B per cell)
+            if (can_defer && c->host_lag && c->rr_byproduct && it + 2 == c->p_iters_hint && it + 1 < maxiter) {
+                deferred = true;
+                deferred_gen = gen;
+                deferred_rr_slot = RR_HIST_OFF + ((it + 1) & 7);
                 ++it;
                 continue;
             }

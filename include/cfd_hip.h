@@ -408,7 +408,8 @@ int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, doub
  * residual norms), "plane_swap" (1 / 0: Chebyshev results adopted by pointer exchange / copied), "xcd_map", "mg_gamma",
  * "mg_om0" .. "mg_om2" (smoother dampings), "mg_f32" (1 / 0: the multigrid levels of the pressure preconditioner carry
  * face coefficients rounded to single precision -- the Krylov operator stays double, the solution is unchanged),
- * "mg_v32_emul" (measurement aid).  INTEGRATION.md section 4 has the table.  No counterpart in the reference.     */
+ * "mg_v32_emul" (measurement aid), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
+ * next pre-smoothing pass / by its own pass).  INTEGRATION.md section 4 has the table.  No counterpart in the reference.     */
 int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
 /* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels
  * its run went through: [0] 4-iteration Chebyshev launches with two right-hand sides, [1] with one, [2] 2-iteration
