@@ -207,6 +207,15 @@ def rehearsal_env(rank):
     os.environ.setdefault("NCCL_IB_DISABLE", "1")
 
 
+def _rccl_probe(dev):
+    """None if the library can reach RCCL on this rank (dlopen + ncclGetUniqueId), else the error text."""
+    try:
+        check(dev.lib.cfd_rccl_unique_id(C.create_string_buffer(_lib.RCCL_ID_BYTES), _lib.RCCL_ID_BYTES))
+    except Exception as e:      # noqa: BLE001
+        return str(e)
+    return None
+
+
 def attach_rccl(dev, group=None):
     """Give the slab context the library's own RCCL communicator (collective over `group`)."""
     import torch.distributed as dist
@@ -259,9 +268,33 @@ def slab_device(ni, nj_global, device=0, group=None, min_slab_rows=None, transpo
     dev._ws, dev._stream, dev.comm = ws, stream, comm     # keep alive as long as the context
     dev.j_offset, dev.nj_global, dev.rank, dev.nranks = j_off, int(nj_global), rank, world
     import os
-    transport = transport or os.environ.get("CFD_SLAB_TRANSPORT") or \
-        ("rccl" if dist.get_backend(group) == "nccl" else "torch")
-    if transport == "rccl":
+    asked = transport or os.environ.get("CFD_SLAB_TRANSPORT")
+    transport = asked or ("rccl" if dist.get_backend(group) == "nccl" else "torch")
+    dev.transport_note = None
+    if transport == "rccl" and not asked:
+        # Default choice: if the library's own communicator cannot be built, all ranks agree to use the
+        # torch.distributed callbacks instead (same RCCL underneath, host code between the kernels) and say so.
+        # Two agreement points, so that no rank is left alone inside a collective: RCCL loadable by the library on
+        # every rank (before the id is broadcast), then the communicator built on every rank.
+        def all_ok(err):
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=f"cuda:{device}")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+        err = _rccl_probe(dev)
+        if all_ok(err):
+            try:
+                attach_rccl(dev, group)
+            except Exception as e:      # noqa: BLE001 - any failure of the native path leads to the same fall-back
+                err = str(e)
+            native = all_ok(err)
+        else:
+            native = False
+        if not native:
+            comm.install(lib, dev._h)       # cfd_set_comm releases a communicator this rank may have built
+            transport = "torch"
+            dev.transport_note = "library-native RCCL communicator not available (%s): torch.distributed callbacks" % \
+                (err or "failed on another rank")
+    elif transport == "rccl":
         attach_rccl(dev, group)
     elif transport == "torch":
         comm.install(lib, dev._h)

@@ -7,6 +7,7 @@ Every rank shares GPU 0 (the test box has one GPU).  mode selects process-group 
     gloo        gloo group, torch.distributed callbacks staged through the host
     rccl        gloo group for the host side, the library's native RCCL transport for the slabs
     nccl        nccl group, native RCCL transport (what a multi-GPU node runs by default)
+    nccl-fallback   as nccl, but the native transport is reported unavailable on the last rank
     nccl-torch  nccl group, torch.distributed callbacks on device views
 The RCCL modes rehearse on one device with one fake host id per rank (cfd_amd.slab.rehearsal_env).
 Rank 0 writes <out_dir>/result.npz.
@@ -137,7 +138,7 @@ def kernel_check(name, out_dir, rank, world):
 def main():
     name, out_dir, mode = sys.argv[1], Path(sys.argv[2]), sys.argv[3]
     backend, transport = {"gloo": ("gloo", "torch"), "rccl": ("gloo", "rccl"), "nccl": ("nccl", None),
-                          "nccl-torch": ("nccl", "torch")}[mode]
+                          "nccl-torch": ("nccl", "torch"), "nccl-fallback": ("nccl", None)}[mode]
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     work = out_dir / f"rank{rank}"
     work.mkdir(parents=True, exist_ok=True)
@@ -154,6 +155,10 @@ def main():
             os.environ.pop("CFD_SLAB_TRANSPORT", None)
         kw = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        if mode == "nccl-fallback" and rank == world - 1:
+            # the library cannot reach RCCL on the last rank: every rank must agree on the torch.distributed callbacks
+            import cfd_amd.slab
+            cfd_amd.slab._rccl_probe = lambda dev: "simulated: RCCL not loadable"
     if name == "mesh_from_rect":
         return mesh_from_rect_check(out_dir, rank, world)
     if name.startswith("kernels:"):

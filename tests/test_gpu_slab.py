@@ -116,6 +116,18 @@ def test_rccl_transports(mode, world, tmp_path):
     assert np.all(kn["counts"] > 0) and not np.any(k1["counts"])
 
 
+def test_default_transport_falls_back_to_the_callbacks_together(tmp_path):
+    """Default transport under an nccl group is the library's own communicator; when one rank cannot build it, all
+    ranks take the torch.distributed callbacks (agreed by an all-reduce before anybody enters an RCCL collective of
+    the library) and the run is the single-rank run."""
+    case = "kernels:channel_komega_48x64"
+    k1 = _run(case, 1, tmp_path / "k1")
+    kn = _run(case, 2, tmp_path / "k2", 16, "nccl-fallback")
+    assert np.abs(k1["z"] - kn["z"]).max() <= 1e-12 * np.abs(k1["z"]).max()
+    assert int(k1["mom_iters"]) == int(kn["mom_iters"]) and int(k1["p_iters"]) == int(kn["p_iters"])
+    assert int(kn["native"]) == 0 and np.all(kn["counts"] > 0)
+
+
 @pytest.mark.parametrize("mode,min_rows", [("rccl", 16), ("rccl", 512), ("gloo", 16)])
 def test_world8_rehearsal_on_one_gpu(mode, min_rows, tmp_path):
     """Eight ranks (the world size of BASELINE's config) sharing this box's one GPU: a 64 x 256 channel as eight
