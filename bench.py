@@ -47,7 +47,8 @@ PMC_KERNEL_OF_PROBE = {0: "k_cg_pq", 8: "k_chebk<2,4", 9: "k_chebk<1,4", 7: "k_m
 
 def load_pmc_traffic():
     """bytes per cell and launch of the probed kernels from the newest committed PMC summary (tools/pmc_summary.py)."""
-    files = sorted((REPO / "profiles").glob("r2*_pmc8192_bytes_per_cell.csv"))
+    # laminar passes only: the k-omega passes are named r2?_komega_pmc8192_* (tools/profile_komega.sh)
+    files = sorted(f for f in (REPO / "profiles").glob("r2*_pmc8192_bytes_per_cell.csv") if "komega" not in f.name)
     if not files:
         return None, {}
     out = {}
