@@ -635,6 +635,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "rr_byproduct") c->rr_byproduct = iv ? 1 : 0;
     else if (n == "mg_f32") { c->mg_f32 = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_dirs") { c->mg_line_dirs = iv ? 1 : 0; c->p_built = false; }
+    else if (n == "mg_odd_fix") { c->mg_odd_fix = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }
     else if (n == "mg_line_omega") { if (!(value > 0.0 && value <= 1.0)) { set_error("mg_line_omega: (0, 1]"); return CFD_E_ARG; } c->mg_line_omega = value; }
     else { set_error("cfd_set_option: unknown option '%s'", name); return CFD_E_ARG; }

@@ -377,6 +377,7 @@ struct Ctx {
     int mg_v32_emul = 0;           // measurement aid: the fused V-cycle kernels round what they store (x, coarse right-hand side, correction) to single precision
     int mg_f32 = 1;                // fused V-cycle levels read their face coefficients in single precision
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
+    int mg_odd_fix = 1;            // coarse faces next to a single-cell last aggregate (odd fine count) scaled by the real centre distance (0: by the coarsening factor, as round 1 did; 5000^2: 10.2 -> 8 PCG iterations)
     int mg_line_dirs = 1;          // 1: a line-smoothed level sweeps both directions; 0: only those whose own coupling ratio exceeds the threshold (wall-graded 8192^2 channel: 79 iterations instead of 12, the wide centre cells need the i-lines)
     double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this
     double mg_line_omega = 0.8;

@@ -548,8 +548,10 @@ __global__ void k_mg_prolong(Geo g, Tiling T, Geo gc, int fi, int fj, const doub
     }
 }
 // coarse face conductances: parallel sum across the face, series (1/f) along its normal
+// A fine level with an odd count ends in an aggregate of ONE cell: the faces between it and a two-cell aggregate join
+// centres 1.5 fine spacings apart (the periodic seam included), its boundary face keeps the fine half spacing.
 __global__ void k_mg_coarsen(Geo g, const double *ci, const double *cj, const double *D, Geo gc, Tiling Tc, int fi, int fj,
-                             double *cic, double *cjc, double *ec) {
+                             int per_i, int per_j, int odd_fix, double *cic, double *cjc, double *ec) {
     TILE_LOOP(gc, Tc) {
         const size_t cc = gc.cell(i, j);
         const size_t P = g.pitch;
@@ -570,10 +572,21 @@ __global__ void k_mg_coarsen(Geo g, const double *ci, const double *cj, const do
                 const size_t c = g.cell(ifn, jf);
                 extra += D[c] - (ci[c] + ci[c + 1] + cj[c] + cj[c + P]);
             }
-        cic[cc] = w / fi;
-        if (i == gc.ni - 1) cic[cc + 1] = e_hi / fi;
-        cjc[cc] = s / fj;
-        if (j == gc.nj - 1) cjc[cc + gc.pitch] = n_hi / fj;
+        double dw = fi, de = fi, ds = fj, dn = fj;
+        if (odd_fix && fi == 2 && (g.ni & 1) && gc.ni > 1) {
+            if (i == gc.ni - 1) dw = 1.5;
+            if (i == 0 && per_i) dw = 1.5;
+            de = per_i ? 1.5 : 1.0;
+        }
+        if (odd_fix && fj == 2 && (g.nj & 1) && gc.nj > 1) {
+            if (j == gc.nj - 1) ds = 1.5;
+            if (j == 0 && per_j) ds = 1.5;
+            dn = per_j ? 1.5 : 1.0;
+        }
+        cic[cc] = w / dw;
+        if (i == gc.ni - 1) cic[cc + 1] = e_hi / de;
+        cjc[cc] = s / ds;
+        if (j == gc.nj - 1) cjc[cc + gc.pitch] = n_hi / dn;
         const int fm = fi > fj ? fi : fj;
         ec[cc] = extra > 0.0 ? extra / fm : 0.0;
     }
@@ -2599,8 +2612,8 @@ int build_pressure_hierarchy(Ctx *c) {
         factors(F.g, cg, fi, fj);
         const Tiling Tc = tiling(cg);
         // C.t is used as the scratch for the diagonal extra
-        hipLaunchKernelGGL(k_mg_coarsen, dim3(Tc.blocks), block2d(), 0, st, F.g, F.ci, F.cj, F.D, cg, Tc, fi, fj, ci_t,
-                           cj_t, C.t);
+        hipLaunchKernelGGL(k_mg_coarsen, dim3(Tc.blocks), block2d(), 0, st, F.g, F.ci, F.cj, F.D, cg, Tc, fi, fj,
+                           c->pp_per_i, c->pp_per_j, c->mg_odd_fix, ci_t, cj_t, C.t);
         if (c->mg_f32) {
             // before the diagonal is summed from them: D stays the exact sum of the faces every kernel reads
             const size_t n = cg.plane_elems();
