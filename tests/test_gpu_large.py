@@ -492,3 +492,28 @@ def test_fused_correction_at_the_benchmark_size():
     for a, b in zip(out[1][0], out[0][0]):
         assert np.array_equal(mask_corners(a), mask_corners(b))
     assert out[1][1]["p_iters"] == out[0][1]["p_iters"] and out[1][1]["mom_iters"] == out[0][1]["mom_iters"]
+
+
+@pytest.mark.parametrize("n", [750, 1001])
+def test_odd_levels_scale_coarse_faces_by_the_centre_distance(n):
+    """Hierarchies with odd levels (750 -> 375 -> 188 ..., 1001 -> 501 -> 251 ...): the coarse faces next to the
+    one-cell last aggregate are scaled by the distance between the aggregate centres (mg_odd_fix = 1, default).  The
+    preconditioner changes, the solution does not: same fields to the solver tolerance, and not more MG-PCG iterations
+    than with the plain factor-two scaling."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for fix in (1, 0):
+        dev, ctl, cfg = bench.setup_device(n, False, 2, 1e-10, 0, tuning={"mg_odd_fix": fix})
+        its = 0
+        for step in range(3):
+            advance_one_step(dev, ctl, step)
+            its += dev.stats()["p_iters"]
+        out[fix] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P)], its)
+        dev.close()
+    assert out[1][1] <= out[0][1], (out[1][1], out[0][1])
+    for a, b in zip(out[1][0], out[0][0]):
+        a, b = mask_corners(a), mask_corners(b)
+        scale = max(np.abs(a).max(), 1e-30)
+        assert np.abs(a - b).max() <= 1e-7 * scale, np.abs(a - b).max() / scale
