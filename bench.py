@@ -6,7 +6,8 @@ of the synthetic periodic channel of SURVEY.md 8(d) on an N x N cell mesh, all p
 resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus / step time.
 
     python bench.py --gpus 1 --steps 20 --warmup 5            (default size 8192)
-    torchrun ... bench.py --gpus N ...                        (one rank per GPU)
+    python bench.py --gpus N ...                              (starts N ranks itself, one per GPU, relays rank 0's line)
+    torchrun ... bench.py --gpus N ...                        (ranks from the launcher's environment)
 
 The JSON line also carries
   roofline     : the probed hot kernel with the largest share of device time (found live: one untimed step per
@@ -203,6 +204,27 @@ KERNEL_NAMES = {
     10: "MG pre-smoother with the PCG residual update folded in (k_mg_down_k<true,3,true>)",
     7: "MG post-smoother, finest level: prolong + 3 fused Jacobi sweeps + (r,z) (k_mg_up_k<true,3>)"}
 CANDIDATES = (0, 8, 9, 7, 1, 10, 2)
+# ids that are instantiations of ONE kernel are one entry when the `roofline` kernel is chosen (the per-instantiation
+# split is reported beside it): k_cg_pq's three forms already share id 0
+GROUPS = {"k_chebk": (8, 9), "k_cg_pq": (0,), "k_mg_up_k": (7,), "k_mg_down_k": (1, 10), "k_correct_flux": (2,)}
+GROUP_NAMES = {
+    "k_chebk": "momentum Chebyshev, four fused iterations per launch (k_chebk<2,4> on u and v, k_chebk<1,4> once one of "
+               "them has converged)",
+    "k_cg_pq": KERNEL_NAMES[0],
+    "k_mg_up_k": KERNEL_NAMES[7],
+    "k_mg_down_k": "MG pre-smoother, finest level: 3 fused Jacobi sweeps + residual + restrict, with / without the PCG "
+                   "residual update folded in (k_mg_down_k<true,3,*>)",
+    "k_correct_flux": KERNEL_NAMES[2]}
+# probed only for the byte / time accounting of the pressure solve: PCG residual update, last x update, pressure RHS
+PRESSURE_IDS = (0, 1, 10, 7, 11, 12, 13)
+
+
+def merge(entries):
+    """(launches, mean us, mean bytes per cell) of several probe ids taken together."""
+    cnt = sum(e[0] for e in entries)
+    if not cnt:
+        return (0, 0.0, 0.0)
+    return (cnt, sum(e[0] * e[1] for e in entries) / cnt, sum(e[0] * e[2] for e in entries) / cnt)
 
 
 def second_leg(args, n, world, local, barrier, torch, dist, strong):
@@ -245,6 +267,93 @@ def second_leg(args, n, world, local, barrier, torch, dist, strong):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` without a launcher: start N child processes of this script, one rank each, with the
+    rendezvous variables torch.distributed.run would set (127.0.0.1, a free port), wait for them and relay rank 0's
+    JSON line as this process's only stdout line.  Runs BEFORE torch or the HIP library is imported here: the parent
+    never touches the GPU and never replaces itself (no exec).  A rank that fails takes the others with it (exact
+    PIDs) and the parent leaves with its code."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "CFD_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, "-u", str(Path(__file__).resolve())] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    import threading
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(n_ranks))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code
+                print(f"bench.py: rank {r} of {n_ranks} exited with code {code}", file=sys.stderr, flush=True)
+                break
+        time.sleep(0.05)
+    for r in live:               # a failed rank leaves the others inside a collective: end them
+        procs[r].terminate()
+    for r in live:
+        try:
+            procs[r].wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    reader.join(timeout=10)
+    result = None
+    for ln in lines:
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            result = ln                      # the last JSON object rank 0 printed
+        elif ln:
+            print(ln, file=sys.stderr)
+    if rc == 0 and result is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    if rc == 0:
+        if json.loads(result).get("n_gpus") != n_ranks:
+            print(f"bench.py: rank 0 reported n_gpus = {json.loads(result).get('n_gpus')}, expected {n_ranks}",
+                  file=sys.stderr, flush=True)
+            return 1
+        print(result, flush=True)
+    return rc if rc > 0 else (1 if rc else 0)
+
+
+def rehearse_launch(world, rank, backend):
+    """--rehearse-launch: the launch / rendezvous / relay path alone, on the CPU (tests/test_bench_launch.py): every rank
+    joins a gloo group, the ranks are counted by an all-reduce and rank 0 prints a line of the bench's shape."""
+    import torch
+    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "cell-updates/s per outer step", "value": None, "n_gpus": world, "launch_rehearsal": True,
+                          "ranks_seen_by_all_reduce": seen,
+                          "self_launched": os.environ.get("CFD_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,16 +393,32 @@ def main():
                     help="N > 1: skip the leg in the other scaling mode that follows the timed region")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use GPU 0 (with --backend gloo), numbers are not a measurement")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="test aid: run only the launch / rendezvous / relay path (gloo, no GPU) and print a stub line")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # ---- N > 1 without a launcher: this process becomes the launcher (before torch / HIP are imported)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a launcher's WORLD_SIZE and --gpus disagree: the line would claim something that did not run
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE = {world} ranks")
+    if args.rehearse_launch:
+        return rehearse_launch(world, rank, args.backend)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if not args.shared_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible "
+                         f"(--shared-gpu rehearses several ranks on one GPU; its numbers are not a measurement)")
     if args.shared_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -357,6 +482,7 @@ def main():
         info = advance_one_step(dev, ctl, step)
         step += 1
     dev.synchronize()
+    dev.set_option("probe_capacity", min(16384, 160 * (args.steps + 1) * max(1, args.max_iter) // 2 + 64))
     dev.probe(L.PROBE_ALL if probe_id < 0 else probe_id)
     comm0 = dev.comm_counts()
     phase0 = dev.comm_counts_by_phase()
@@ -377,12 +503,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     per_kernel = {}
+    group = None
+    pressure_probe = None
     if probe_id < 0:
         for pid in CANDIDATES:
             per_kernel[pid] = dev.probe_read(with_bytes=True, kernel=pid)
-            shares[pid] = per_kernel[pid][0] * per_kernel[pid][1]
-        probe_id = max(shares, key=shares.get)
-        n_probe, probe_us, probe_bpc = per_kernel[probe_id]
+        pressure_probe = {pid: dev.probe_read(with_bytes=True, kernel=pid) for pid in PRESSURE_IDS}
+        for name, ids in GROUPS.items():
+            shares[name] = sum(per_kernel[pid][0] * per_kernel[pid][1] for pid in ids)
+        group = max(shares, key=shares.get)
+        n_probe, probe_us, probe_bpc = merge([per_kernel[pid] for pid in GROUPS[group]])
+        probe_id = GROUPS[group][0]
     else:
         n_probe, probe_us, probe_bpc = dev.probe_read(with_bytes=True)
     dev.probe(-1)
@@ -403,8 +534,10 @@ def main():
     # more step each with the event-pair probe on that kernel
     others = {}
     for pid in CANDIDATES:
-        if pid == probe_id:
+        if pid == probe_id and group is None:
             continue
+        if group is not None and pid in GROUPS[group]:
+            continue                     # the headline kernel itself (its instantiations are listed with it)
         if pid in per_kernel:            # timed inside the timed region together with the headline kernel
             others[pid] = per_kernel[pid]
             continue
@@ -442,15 +575,21 @@ def main():
         achieved = probe_bpc * cells_gpu / (probe_us * 1e-6) / 1e9 if n_probe else 0.0
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": (pmc[probe_id] * cells_gpu
-                                if n == 8192 and world == 1 and not args.turbulent and probe_id in pmc else None),
+                    "traffic": (sum(pmc[pid] * per_kernel[pid][0] for pid in GROUPS[group]) / max(1, n_probe) * cells_gpu
+                                if group is not None and n == 8192 and world == 1 and not args.turbulent and args.mesh == "uniform"
+                                and all(pid in pmc for pid in GROUPS[group]) else None),
                     "traffic_unit": f"bytes per launch (PMC, profiles/{pmc_file})" if pmc_file else None,
-                    "kernel": KERNEL_NAMES.get(probe_id, str(probe_id)),
+                    "kernel": GROUP_NAMES[group] if group is not None else KERNEL_NAMES.get(probe_id, str(probe_id)),
+                    "instantiations": None if group is None or len(GROUPS[group]) < 2 else [
+                        {"kernel": KERNEL_NAMES[pid], "launches_timed": per_kernel[pid][0], "avg_us": per_kernel[pid][1],
+                         "bytes_per_cell": per_kernel[pid][2],
+                         "frac": (per_kernel[pid][2] * cells_gpu / (per_kernel[pid][1] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                                  if per_kernel[pid][0] else None)} for pid in GROUPS[group]],
                     "avg_us": probe_us, "launches_timed": n_probe,
                     "bytes_per_cell": probe_bpc,
                     "bytes_note": "mean ALGORITHMIC bytes per cell of the timed launches, reported by the library per launch "
                                   "(PCG direction step: 40 / 56 / 64 B for the first / second / later steps of a solve)",
-                    "share_of_probed_device_time": (shares[probe_id] / sum(shares.values()) if shares else None)}
+                    "share_of_probed_device_time": (shares[group] / sum(shares.values()) if shares else None)}
         it = np.array(iters)
         if world == 1:
             par = "1 GPU"
@@ -470,7 +609,17 @@ def main():
                                     f"{', wall-graded mesh with max / min dy = 20' if args.mesh == 'graded' else ''}), SIMPLE ")
                                    + f"max_iter={args.max_iter}, continuity_tol=0, cfl=cfl_diff=0.5, "
                                    f"dt_max={cfg['time']['dt_max']:.3g}, rtol={args.tol:g}",
+                       "precision_note": ("fp64 arithmetic, fp64 fields, fp64 Krylov recurrences and stopping tests; the "
+                                          "multigrid PRECONDITIONER of the pressure solve stores its face coefficients, its "
+                                          "finest-level pre-smoothed iterate and its result z in fp32 (option mg_f32 = 1, "
+                                          "default): storage only, the converged p' is that of the fp64 system"
+                                          if "mg_f32=0" not in (args.tuning or "").replace(" ", "") else
+                                          "fp64 arithmetic and storage throughout (mg_f32 = 0)"),
                        "cells_per_gpu": cells_gpu,
+                       "launcher": ("bench.py --gpus N started the ranks itself" if os.environ.get("CFD_BENCH_SELF_LAUNCHED") == "1"
+                                    else ("external launcher (WORLD_SIZE from the environment)" if world > 1 else "single process")),
+                       "rccl_ranks": dev.rccl_ranks() if world > 1 else None,
+                       "process_group": None if world == 1 else {"backend": args.backend, "world_size": dist.get_world_size()},
                        "parallelism": par + ("" if world == 1 else
                                              ", halo rows + all-reduce + coarse-level all-gather "
                                              + ("enqueued by the library over RCCL" if dev.transport == "rccl" else
@@ -495,24 +644,47 @@ def main():
                  "traffic": pmc[pid] * cells_gpu if (n == 8192 and world == 1 and not args.turbulent and pid in pmc) else None}
                 for pid, (cnt, us, bpc) in others.items()],
         }
-        # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes of one
-        # MG-PCG iteration over all levels: finest level 64 (k_cg_pq) + 24 (k_cg_r) + 34 (k_mg_down)
-        # + 42 (k_mg_up) B/cell (diagonal recomputed from the face planes on every level of this all-Neumann /
-        # periodic system), coarser levels (34 + 42) / 3 B/cell.  With the single-precision face planes of the fused
-        # V-cycle kernels (option mg_f32, default on) each of the two passes reads 8 B per cell less.
-        # and the finest level keeps its pre-smoothed iterate in single precision (4 B less per pass).
-        f32 = 0.0 if "mg_f32=0" in (args.tuning or "").replace(" ", "") else 8.0
-        # ... and hands z to the direction step in single precision (4 B less in each of the two kernels)
-        pcg_bytes_per_cell_iter = (64 - 0.5 * f32) + 24 + (34 - 1.5 * f32) + (42 - 2.0 * f32) + ((34 - f32) + (42 - f32)) / 3.0
+        # second BASELINE metric: achieved HBM GB/s of the pressure solve.  Algorithmic bytes = what the launches of the
+        # timed steps actually moved (the library reports the bytes of every probed launch: direction steps 36 / 52 / 60 B,
+        # pre-smoother 22 B plain and 38 B with the residual update folded in, post-smoother 26 B, k_cg_r / k_cg_xlast
+        # 24 B only on the iterations that run them, pressure right-hand side 112 B) + the coarser levels of each V-cycle
+        # ((down + up) bytes per coarse cell x the cells of levels 1.. = 1/3 of the finest level's).
+        f32 = "mg_f32=0" not in (args.tuning or "").replace(" ", "")
+        coarse_bytes_per_vcycle = ((26.0 + 30.0) if f32 else (34.0 + 42.0)) / 3.0
         n_solves = extra_steps * args.max_iter
         press_s = phases["press"] / n_solves
         mean_p_it = float(np.mean(p_its))
+        if pressure_probe is not None and pressure_probe[7][0] > 0 and args.mesh == "uniform":
+            timed_solves = args.steps * args.max_iter
+            fine = sum(cnt * bpc for cnt, _, bpc in pressure_probe.values()) / timed_solves
+            vcycles = pressure_probe[7][0] / timed_solves
+            bytes_per_solve = fine + coarse_bytes_per_vcycle * vcycles
+            mix = {"direction_steps": pressure_probe[0][0] / timed_solves,
+                   "presmoother_plain": pressure_probe[1][0] / timed_solves,
+                   "presmoother_with_residual_update": pressure_probe[10][0] / timed_solves,
+                   "postsmoother": pressure_probe[7][0] / timed_solves,
+                   "residual_update_passes": pressure_probe[11][0] / timed_solves,
+                   "last_x_update": pressure_probe[12][0] / timed_solves,
+                   "rhs_passes": pressure_probe[13][0] / timed_solves,
+                   "coarse_level_bytes_per_cell_per_vcycle": coarse_bytes_per_vcycle}
+            note = ("algorithmic bytes from the launch mix of the timed steps (per solve); time = device time of the pressure "
+                    "phase (right-hand side kernel, solve, host residual checks) over the two steps that follow the timed region")
+        else:
+            # line-smoothed / curvilinear workloads and forced single-kernel probes: nominal V(3,3)-PCG bytes per iteration
+            f8 = 8.0 if f32 else 0.0
+            per_it = (64 - 0.5 * f8) + 24 + (34 - 1.5 * f8) + (42 - 2.0 * f8) + ((34 - f8) + (42 - f8)) / 3.0
+            bytes_per_solve = per_it * mean_p_it + 112.0
+            mix = None
+            note = ("nominal bytes of a point-smoothed V(3,3)-PCG iteration x iterations + right-hand side (line-smoothed levels "
+                    "move more: this UNDERSTATES the traffic of --mesh graded / annulus)")
         out["pressure_solve"] = {
             "ms_per_solve": 1e3 * press_s, "iterations": mean_p_it,
-            "algorithmic_bytes_per_cell_per_iteration": pcg_bytes_per_cell_iter,
-            "achieved_GBps": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 if press_s > 0 else None,
-            "frac_of_hbm_peak": pcg_bytes_per_cell_iter * mean_p_it * cells_gpu / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
-            "note": "includes the pressure right-hand side kernel and the host residual checks of the solve"}
+            "algorithmic_bytes_per_cell_per_solve": bytes_per_solve,
+            "algorithmic_bytes_per_cell_per_iteration": bytes_per_solve / mean_p_it if mean_p_it else None,
+            "launches_per_solve": mix,
+            "achieved_GBps": bytes_per_solve * cells_gpu / press_s / 1e9 if press_s > 0 else None,
+            "frac_of_hbm_peak": bytes_per_solve * cells_gpu / press_s / 1e9 / HBM_PEAK_GBS if press_s > 0 else None,
+            "note": note}
         out["weak_scaling_leg" if strong else "strong_scaling_leg"] = other_leg
         out["settle_s"] = args.settle     # untimed work on a separate 1024^2 context before the warm-up steps (--settle)
         out["phase_ms_per_step"] = {k: 1e3 * v / extra_steps for k, v in phases.items()}

@@ -137,6 +137,7 @@ SIGNATURES.update({
     "cfd_exchange_field": (C.c_int, [_vp, C.c_int]),
     "cfd_rccl_unique_id": (C.c_int, [_vp, C.c_size_t]),
     "cfd_set_comm_rccl": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "cfd_rccl_ranks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "cfd_comm_counts": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "cfd_comm_counts_by_phase": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
     "cfd_level_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

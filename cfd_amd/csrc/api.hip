@@ -10,8 +10,8 @@
 namespace cfd {
 
 static thread_local char g_err[1024] = "";
-long long g_launches = 0, g_syncs = 0, g_syncs_phase[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-int g_phase = 8;
+std::atomic<long long> g_launches{0}, g_syncs{0}, g_syncs_phase[9];
+thread_local int g_phase = 8;
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -363,6 +363,12 @@ int cfd_set_comm_rccl(cfd_ctx *ctx, const void *id, size_t bytes) {
     return rccl_attach(c, id, bytes);
 }
 
+int cfd_rccl_ranks(cfd_ctx *ctx, int *ranks) {
+    CTX(ctx);
+    if (!ranks) { set_error("cfd_rccl_ranks: null"); return CFD_E_ARG; }
+    return rccl_ranks(c, ranks);
+}
+
 int cfd_comm_counts_by_phase(cfd_ctx *ctx, long long counts[27]) {
     CTX(ctx);
     if (!counts) return CFD_E_ARG;
@@ -613,6 +619,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     const std::string n(name);
     const int iv = (int)value;
     if (n == "cheb_stages") { if (iv != 1 && iv != 2 && iv != 4) { set_error("cheb_stages: 1, 2 or 4"); return CFD_E_ARG; } c->cheb_stages = iv; }
+    else if (n == "probe_capacity") { if (iv < 16 || iv > 16384) { set_error("probe_capacity: 16 .. 16384"); return CFD_E_ARG; } c->probe_capacity = iv; }
     else if (n == "cheb_prefetch") { if (iv != 1 && iv != 2) { set_error("cheb_prefetch: 1 or 2"); return CFD_E_ARG; } c->cheb_prefetch = iv; }
     else if (n == "fuse_nut") c->fuse_nut = iv ? 1 : 0;
     else if (n == "dt_lookahead") c->dt_lookahead = iv ? 1 : 0;
@@ -644,14 +651,14 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
 
 int cfd_host_counters(long long out[2], int reset) {
     if (!out) return CFD_E_ARG;
-    out[0] = cfd::g_launches; out[1] = cfd::g_syncs;
-    if (reset) cfd::g_launches = cfd::g_syncs = 0;
+    out[0] = cfd::g_launches.load(); out[1] = cfd::g_syncs.load();
+    if (reset) { cfd::g_launches.store(0); cfd::g_syncs.store(0); }
     return CFD_OK;
 }
 
 int cfd_host_syncs_by_phase(long long out[9], int reset) {
     if (!out) return CFD_E_ARG;
-    for (int q = 0; q < 9; ++q) { out[q] = cfd::g_syncs_phase[q]; if (reset) cfd::g_syncs_phase[q] = 0; }
+    for (int q = 0; q < 9; ++q) { out[q] = cfd::g_syncs_phase[q].load(); if (reset) cfd::g_syncs_phase[q].store(0); }
     return CFD_OK;
 }
 
@@ -1376,7 +1383,11 @@ int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, in
 int cfd_probe(cfd_ctx *ctx, int kernel) {
     CTX(ctx);
     CFD_HIP(hipStreamSynchronize(c->stream));
-    const size_t want = kernel == CFD_PROBE_ALL ? 16384 : 4096;
+    // event pairs for as many launches as the caller said it will time (option "probe_capacity": bench.py asks for what
+    // its steps need, about 130 launches per step), not for the largest run imaginable: round 2 created 2 x 16384
+    // events here and, until a7df7d1, recorded each of them once at creation -- the one thing that crashed under
+    // rocprofv3, whose tool library wraps every event record
+    const size_t want = (size_t)c->probe_capacity;
     if (kernel >= 0 && c->probe_e0.size() < want) {
         const size_t have = c->probe_e0.size();
         c->probe_e0.resize(want);

@@ -27,6 +27,7 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;     // optional: only cfd_rccl_ranks asks for it
 };
 
 RcclApi g_rccl;
@@ -54,6 +55,7 @@ int load_rccl() {
                     bind(g_rccl.AllReduce, "ncclAllReduce") && bind(g_rccl.AllGather, "ncclAllGather") &&
                     bind(g_rccl.GetErrorString, "ncclGetErrorString");
     if (!ok) { g_rccl = RcclApi{}; return CFD_E_STATE; }
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.lib, "ncclCommCount");
     return CFD_OK;
 }
 
@@ -77,6 +79,16 @@ int rccl_unique_id(void *id, size_t bytes) {
     ncclUniqueId u;
     CFD_RCCL(g_rccl.GetUniqueId(&u));
     std::memcpy(id, &u, sizeof(u));
+    return CFD_OK;
+}
+
+// Ranks of the library's own communicator as RCCL itself reports them (0: no native communicator): what a
+// benchmark line quotes as proof that N processes really joined one communicator.
+int rccl_ranks(Ctx *c, int *ranks) {
+    *ranks = 0;
+    if (!c->comm.rccl) return CFD_OK;
+    if (!g_rccl.CommCount) { set_error("RCCL library lacks ncclCommCount"); return CFD_E_STATE; }
+    CFD_RCCL(g_rccl.CommCount((ncclComm_t)c->comm.rccl, ranks));
     return CFD_OK;
 }
 

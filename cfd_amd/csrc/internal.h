@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -91,15 +92,20 @@ void set_error(const char *fmt, ...);
 
 // host-side cost counters (cfd_host_counters): kernel launches and blocking stream synchronisations issued by the
 // library in this process -- the two quantities that bound the step time of small meshes and of thin j-slabs
-extern long long g_launches, g_syncs, g_syncs_phase[9];      // [phase id of api.hip's Phase, 8 = outside any phase]
-extern int g_phase;
+// (process wide and shared by every context and host thread, hence atomic; the phase a thread is in is its own)
+extern std::atomic<long long> g_launches, g_syncs, g_syncs_phase[9];      // [phase id of api.hip's Phase, 8 = outside any phase]
+extern thread_local int g_phase;
+inline void count_sync() {
+    g_syncs.fetch_add(1, std::memory_order_relaxed);
+    g_syncs_phase[g_phase].fetch_add(1, std::memory_order_relaxed);
+}
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                    \
     do {                                                                               \
-        ++cfd::g_launches;                                                             \
+        cfd::g_launches.fetch_add(1, std::memory_order_relaxed);                       \
         kernel<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__);                   \
     } while (0)
-#define hipStreamSynchronize(stream) (++cfd::g_syncs, ++cfd::g_syncs_phase[cfd::g_phase], (hipStreamSynchronize)(stream))
+#define hipStreamSynchronize(stream) (cfd::count_sync(), (hipStreamSynchronize)(stream))
 
 #define CFD_HIP(expr)                                                                         \
     do {                                                                                      \
@@ -424,6 +430,7 @@ struct Ctx {
 
     // live kernel probe (bench.py): HIP-event pairs around every launch of one kernel id, or (CFD_PROBE_ALL) of every id
     int probe_kernel = -1;
+    int probe_capacity = 2048;    // launches a probe run can time (option "probe_capacity")
     std::vector<hipEvent_t> probe_e0, probe_e1;
     std::vector<int> probe_id;
     std::vector<double> probe_b;  // algorithmic bytes per cell of each timed launch (they differ per launch)
@@ -505,6 +512,7 @@ int all_gather_rows(Ctx *c, const double *src, double *dst, size_t elems_each);
 int rccl_unique_id(void *id, size_t bytes);
 int rccl_attach(Ctx *c, const void *id, size_t bytes);
 void rccl_release(Ctx *c);
+int rccl_ranks(Ctx *c, int *ranks);
 inline double global_cells(const Ctx *c) {
     return (double)c->g.ni * (double)(c->comm.nranks > 1 ? c->comm.nj_global : c->g.nj);
 }

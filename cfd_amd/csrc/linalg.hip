@@ -87,8 +87,7 @@ int read_scalars_begin(Ctx *c, int off, int n) {
     return CFD_OK;
 }
 int read_scalars_end(Ctx *c, int off, int n, double *host) {
-    ++g_syncs_phase[g_phase];
-    ++g_syncs;       // counted like a stream synchronisation (the host blocks), though the GPU need not drain
+    count_sync();     // counted like a stream synchronisation (the host blocks), though the GPU need not drain
     CFD_HIP(hipEventSynchronize(c->ev_read));
     for (int q = 0; q < n; ++q) host[q] = c->h_scal[off + q];
     return CFD_OK;
@@ -3448,7 +3447,9 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
                 ++it;
                 continue;
             }
+            c->probe_begin(11);
             hipLaunchKernelGGL(k_cg_r, grid, blk, 0, st, g, T, S, gen, q, r, c->partials, c->nts(g));
+            c->probe_end(11, 24.0);
         } else {
             hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);
             CFD_TRY(halo_exchange(c, g, 1, p));
@@ -3493,8 +3494,10 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     c->p_iters_hint = converged_at > 0 ? converged_at : it;
     if (fused && it > 0) {
         if (c->p_ns_active) CFD_TRY(ns_shift_scalar(c, S, (it - 1) & 1, 1, it == 1, p, x));
+        c->probe_begin(12);
         hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, it == 1, p,
                            c->p_ns_active ? c->scal + 81 : (const double *)nullptr, x);
+        c->probe_end(12, it == 1 ? 16.0 : 24.0);
         CFD_HIP(hipGetLastError());
     } else {
         if (fused) CFD_HIP(hipMemsetAsync(x, 0, g.plane_elems() * sizeof(double), st));
@@ -3586,8 +3589,11 @@ int pressure_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, 
     if (nearly) {
         CFD_HIP(hipMemcpyAsync(c->kry[10], b, c->g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         const int cap = maxiter < 120 ? maxiter : 120;
-        CFD_TRY(pcg_mg(c, b, x, tol, cap, iters, relres));
-        if (*iters >= cap && !(*relres <= accept0)) {
+        // a breakdown of PCG on the slightly non-symmetric stored operator (non-finite (r, r)) is a reason to fall back
+        // as well, not an error of the run: before this regime existed these operators went straight to MG-BiCGStab
+        const int rc_pcg = pcg_mg(c, b, x, tol, cap, iters, relres);
+        if (rc_pcg != CFD_OK && rc_pcg != CFD_E_NUMERIC) return rc_pcg;
+        if (rc_pcg == CFD_E_NUMERIC || (*iters >= cap && !(*relres <= accept0))) {
             CFD_HIP(hipMemcpyAsync(const_cast<double *>(b), c->kry[10], c->g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
             c->stats.p_solver = 1;
             c->p_iters_hint = 0;

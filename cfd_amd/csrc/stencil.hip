@@ -1549,7 +1549,9 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
         ma.nts = c->nts();
         c->kc[KC_FLUX_MARCH] += 1;
         if (fm.nstrips > 1) c->kc[KC_FLUX_MARCH_MULTISTRIP] += 1;
+        c->probe_begin(13);
         LAUNCH_FLUX(fm, (k_flux_march<1, false>), (k_flux_march<1, false, false, 8>), c->g, c->mesh(), f, fm, ma, b, c->partials);
+        c->probe_end(13, 112.0);       // u, v, p, a_P, V, w x 2, n x 4, S x 2 read, b written
     } else {
         hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
     }

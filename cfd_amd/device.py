@@ -55,6 +55,12 @@ class Device:
         check(self.lib.cfd_comm_counts(self._h, None, C.byref(native)))
         return bool(native.value)
 
+    def rccl_ranks(self):
+        """Ranks of the library's own RCCL communicator as RCCL reports them (0: none)."""
+        n = C.c_int(0)
+        check(self.lib.cfd_rccl_ranks(self._h, C.byref(n)))
+        return int(n.value)
+
     @property
     def nj_global(self):
         return self.__dict__.get("_nj_global", self.nj)

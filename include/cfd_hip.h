@@ -145,6 +145,9 @@ int cfd_set_comm(cfd_ctx *ctx, cfd_halo_fn halo, cfd_allreduce_fn allreduce, cfd
 #define CFD_RCCL_ID_BYTES 128
 int cfd_rccl_unique_id(void *id, size_t bytes);
 int cfd_set_comm_rccl(cfd_ctx *ctx, const void *id, size_t bytes);
+/* ranks of the library's own RCCL communicator, read back from RCCL (ncclCommCount); 0 when the context has none
+ * (single rank, or the callback transport).  No counterpart in the reference.                                  */
+int cfd_rccl_ranks(cfd_ctx *ctx, int *ranks);
 /* collectives issued so far by this context: halo exchanges, all-reduces, all-gathers; native = 1 with RCCL */
 int cfd_comm_counts(cfd_ctx *ctx, long long counts[3], int *native);
 /* the same three counts per phase of the outer step, counts[3 * phase + kind]; phases in the order of
@@ -383,10 +386,11 @@ int cfd_pressure_krylov(cfd_ctx *ctx, const double *b, double *x, double tol, in
  * 2 = momentum RHS, 3 = batched momentum SpMV, 4 = residual+restrict, 5 = continuity        */
 int cfd_time_kernel(cfd_ctx *ctx, int kernel, int reps, double *avg_us);
 /* live probe: record a HIP-event pair on the context stream around EVERY launch of one hot
- * kernel while the solver runs, up to 4096 launches (-1 = off): 0 = PCG direction step, 1 = finest-level
+ * kernel while the solver runs, up to "probe_capacity" launches (cfd_set_option, default 2048, at most 16384; -1 = off): 0 = PCG direction step, 1 = finest-level
  * multigrid pre-smoother pass, 10 = the same with the PCG residual update folded in, 7 = post-smoother pass,
  * 2 = momentum right-hand sides (+ continuity, + time-step minima), 8 / 9 = Chebyshev launches with two / one
- * right-hand sides; CFD_PROBE_ALL = all of them at once, up to 16384 launches in all.  cfd_probe_read returns how many
+ * right-hand sides, 11 = PCG residual update, 12 = last PCG solution update, 13 = pressure right-hand side; CFD_PROBE_ALL =
+ * all of them at once.  cfd_probe_read returns how many
  * launches were timed and their average duration, cfd_probe_read_id the same for one kernel of a CFD_PROBE_ALL run.  */
 #define CFD_PROBE_ALL 1000
 int cfd_probe(cfd_ctx *ctx, int kernel);
