@@ -97,6 +97,8 @@ SIGNATURES = {
     "cfd_bulk_velocity": (C.c_int, [_vp, C.c_int, _dp]),
     "cfd_bulk_velocity_noalloc": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "cfd_eddy_viscosity": (C.c_int, [_vp]),
+    "cfd_komega_sources": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    "cfd_effective_diffusivity": (C.c_int, [_vp, C.c_double, C.c_double, _dp]),
     "cfd_momentum_diagonal": (C.c_int, [_vp, C.c_double, C.c_double]),
     "cfd_face_flux": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
     "cfd_grad": (C.c_int, [_vp, C.c_int, _dp]),

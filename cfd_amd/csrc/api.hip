@@ -340,6 +340,7 @@ int cfd_destroy(cfd_ctx *ctx) {
     if (c->own_ws && c->ws) hipFree(c->ws);
     if (c->sst_mem) hipFree(c->sst_mem);
     if (c->line_mem) hipFree(c->line_mem);
+    if (c->semi_mem) hipFree(c->semi_mem);
     if (c->f32_mem) hipFree(c->f32_mem);
     if (c->wall_xy) hipFree(c->wall_xy);
     delete ctx;
@@ -641,6 +642,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "mg_v32_emul") c->mg_v32_emul = iv ? 1 : 0;
     else if (n == "rr_byproduct") c->rr_byproduct = iv ? 1 : 0;
     else if (n == "mg_f32") { c->mg_f32 = iv ? 1 : 0; c->p_built = false; }
+    else if (n == "mg_semi") { c->mg_semi = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_dirs") { c->mg_line_dirs = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_odd_fix") { c->mg_odd_fix = iv ? 1 : 0; c->p_built = false; }
     else if (n == "mg_line_threshold") { if (!(value >= 1.0)) { set_error("mg_line_threshold: >= 1"); return CFD_E_ARG; } c->mg_line_threshold = value; c->p_built = false; }
@@ -1177,6 +1179,24 @@ int cfd_bulk_velocity(cfd_ctx *ctx, int field_id, double *out) {
 
 // ------------------------------------------------------------------ fine-grained entry points
 int cfd_eddy_viscosity(cfd_ctx *ctx) { CTX_MUT(ctx); return launch_eddy_viscosity(c); }
+
+int cfd_komega_sources(cfd_ctx *ctx, const double *grad_u, const double *grad_v, double *source_k, double *source_omega) {
+    CTX_MUT(ctx);
+    if (!grad_u || !grad_v || !source_k || !source_omega) { set_error("cfd_komega_sources: null array"); return CFD_E_ARG; }
+    double *gu[2] = {c->kry[11], c->kry[12]}, *gv[2] = {c->kry[13], c->kry[14]};
+    CFD_TRY(to_device_comp(c, grad_u, 2, gu, CFD_KIND_CELL));
+    CFD_TRY(to_device_comp(c, grad_v, 2, gv, CFD_KIND_CELL));
+    CFD_TRY(launch_komega_sources(c, gu[0], gu[1], gv[0], gv[1], c->kry[9], c->kry[10]));
+    CFD_TRY(from_device(c, c->kry[9], source_k, CFD_KIND_CELL));
+    return from_device(c, c->kry[10], source_omega, CFD_KIND_CELL);
+}
+
+int cfd_effective_diffusivity(cfd_ctx *ctx, double nu, double sigma, double *out) {
+    CTX_MUT(ctx);
+    if (!out) { set_error("cfd_effective_diffusivity: null array"); return CFD_E_ARG; }
+    CFD_TRY(launch_effective_diffusivity(c, nu, sigma, c->kry[9]));
+    return from_device(c, c->kry[9], out, CFD_KIND_CELL_GHOSTED);
+}
 
 int cfd_momentum_diagonal(cfd_ctx *ctx, double dt, double nut_coef) {
     CTX_MUT(ctx);

@@ -196,7 +196,7 @@ __device__ __forceinline__ void store_stream_f32(float *p, float v, int nt) {
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
-    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_COUNT = 16
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_COUNT = 16
 };
 
 // ------------------------------------------------------------------ multigrid level
@@ -218,6 +218,16 @@ struct Level {
     double *lm = nullptr, *linv = nullptr;        // j-blocks
     double *lmi = nullptr, *linvi = nullptr;      // i-blocks
     double aniso = 1.0;           // max over the cells of strong / weak coupling (diagnostic, cfd_level_aniso)
+};
+
+// Semi-coarsened line multigrid (stretched meshes, semi.inc): level l holds ni x (nj >> l) cells; whole i-lines are
+// solved exactly (zebra line Gauss-Seidel over the rows), j is the only direction that is coarsened.
+struct SemiLevel {
+    Geo g;
+    double *ci, *cj, *D;          // operator (level 0: the planes of the finest pressure level)
+    double *x, *b;                // levels >= 1
+    double *lm, *linv, *le;       // Thomas factors of the whole i-lines: multiplier, inverse pivot, c_E / pivot
+    double *z, *rs;               // periodic lines (Sherman-Morrison): T'^-1 u per cell; per row {beta / gamma, 1 / (1 + v.z)}
 };
 
 // V-cycle tail: the levels small enough to live in the LDS of one workgroup are cycled by ONE launch (k_mg_tail)
@@ -383,6 +393,13 @@ struct Ctx {
     int mg_v32_emul = 0;           // measurement aid: the fused V-cycle kernels round what they store (x, coarse right-hand side, correction) to single precision
     int mg_f32 = 1;                // fused V-cycle levels read their face coefficients in single precision
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
+    // stretched meshes: zebra whole-line relaxation along i + semi-coarsening along j (semi.inc) in place of the
+    // alternating block line smoother; chosen when the finest level's coupling ratio exceeds mg_line_threshold
+    int mg_semi = 1;
+    bool semi_on = false;
+    std::vector<SemiLevel> semi;
+    char *semi_mem = nullptr;
+    size_t semi_mem_bytes = 0;
     int mg_odd_fix = 1;            // coarse faces next to a single-cell last aggregate (odd fine count) scaled by the real centre distance (0: by the coarsening factor, as round 1 did; 5000^2: 10.2 -> 8 PCG iterations)
     int mg_line_dirs = 1;          // 1: a line-smoothed level sweeps both directions; 0: only those whose own coupling ratio exceeds the threshold (wall-graded 8192^2 channel: 79 iterations instead of 12, the wide centre cells need the i-lines)
     double mg_line_threshold = 10.0;   // a level is line-smoothed when its strong / weak coupling ratio exceeds this
@@ -468,6 +485,8 @@ inline dim3 grid2d(int nx, int ny) { return dim3((nx + 63) / 64, (ny + 3) / 4, 1
 
 // stencil.hip
 int launch_eddy_viscosity(Ctx *c);
+int launch_komega_sources(Ctx *c, const double *ux, const double *uy, const double *vx, const double *vy, double *sk, double *sw);
+int launch_effective_diffusivity(Ctx *c, double nu, double sigma, double *out);
 int launch_komega_coeffs(Ctx *c, double dt, bool both);   // k-omega: nu_t + conductances in one pass
 int launch_diffusion_ap(Ctx *c, double dt, double nut_coef, double *ai, double *aj, double *ap,
                         const double *nu_plane = nullptr);

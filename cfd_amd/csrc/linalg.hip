@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(256) void k_line_i(OpDev op, LineGeo lg, const doub
 // fused marching kernels: two or three sweeps per pass (a slab cut carries NG = 4 halo rows)
 static inline bool level_fusable(const Ctx *c, int lvl, const Geo &F, const Geo &C) {
     const bool k_ok = c->mg_pre == c->mg_post && (c->mg_pre == 2 || c->mg_pre == 3);
-    if (c->levels[lvl].line) return false;       // line-smoothed levels run their own kernels
+    if (c->levels[lvl].line || c->semi_on) return false;       // line-smoothed levels run their own kernels
     return c->mg_fused && k_ok && F.ni >= 16 && F.nj >= 16 && C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
 }
 static inline MarchGeo march_geo_k(const Geo &g, int K);
@@ -2555,6 +2555,8 @@ __global__ void k_seam_asym(Geo g, const double *ci, const double *cj, int per_i
     if (threadIdx.x == 0) { out[0] = sa[0]; out[1] = sb[0]; }
 }
 
+#include "semi.inc"
+
 int build_pressure_hierarchy(Ctx *c) {
     c->p_iters_hint = 0;
     Level &L0 = c->levels[0];
@@ -2665,6 +2667,10 @@ int build_pressure_hierarchy(Ctx *c) {
             if (L.line_dirs & 1) need += 2 * L.g.plane_elems() * sizeof(double);
             if (L.line_dirs & 2) need += 2 * L.g.plane_elems() * sizeof(double);
         }
+        // stretched mesh: the semi-coarsened line multigrid takes the whole cycle where it can (one rank, frozen operator,
+        // lines of at most SEMI_MAX_NI cells); the levels keep their flags, their block factors are then not needed
+        CFD_TRY(semi_build(c, c->levels[0].line));
+        if (c->semi_on) need = 0;
         if (need > c->line_mem_bytes) {
             if (c->line_mem) CFD_HIP(hipFree(c->line_mem));
             c->line_mem = nullptr;
@@ -2678,6 +2684,7 @@ int build_pressure_hierarchy(Ctx *c) {
             Level &L = c->levels[l];
             if (!L.line) continue;
             ++n_line;
+            if (c->semi_on) continue;
             const size_t pb = L.g.plane_elems() * sizeof(double);
             const LineGeo lg = line_geo(L.g);
             if (L.line_dirs & 1) {
@@ -2838,6 +2845,12 @@ static inline MarchGeo march_geo_w(const Geo &g, int W) {
 static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks,
                        const ResidFuse *rf = nullptr, bool *z_f32 = nullptr) {
     if (z_f32) *z_f32 = false;
+    if (c->semi_on) {
+        if (rf) { set_error("internal: deferred residual update on a semi-coarsened hierarchy"); return CFD_E_STATE; }
+        CFD_TRY(semi_vcycle(c, r, z0, dot_blocks));
+        *zout = z0;
+        return CFD_OK;
+    }
     hipStream_t st = c->stream;
     const int nl = (int)c->levels.size();
     // sweep s of a smoothing pass uses omega (even s) or omega2 (odd s): with omega2 != omega the two

@@ -146,6 +146,41 @@ int launch_eddy_viscosity(Ctx *c) {
     return CFD_OK;
 }
 
+// turbulence._sources_komega (turbulence.py:427-444) for velocity gradients the CALLER computed (the function-level
+// API; the outer step evaluates the same expressions inside k_flux_march<4>): interior cells only.
+__global__ void k_komega_sources(Geo g, const double *k, const double *om, const double *nut, const double *ux, const double *uy,
+                                 const double *vx, const double *vy, double *sk, double *sw) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= g.ni || j >= g.nj) return;
+    const size_t c = g.cell(i, j);
+    const double s2 = 2.0 * (ux[c] * ux[c]) + 2.0 * (vy[c] * vy[c]) + (uy[c] + vx[c]) * (uy[c] + vx[c]);
+    const double ks = fmax(k[c], K_FLOOR), os = fmax(om[c], OMEGA_FLOOR);
+    sk[c] = nut[c] * s2 - 0.09 * ks * os;
+    sw[c] = (5.0 / 9.0) * s2 - (3.0 / 40.0) * (os * os);
+}
+
+int launch_komega_sources(Ctx *c, const double *ux, const double *uy, const double *vx, const double *vy, double *sk, double *sw) {
+    hipLaunchKernelGGL(k_komega_sources, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->k, c->omega, c->nut, ux, uy,
+                       vx, vy, sk, sw);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
+// turbulence.effective_diffusivity, constant-sigma branch (turbulence.py:568-577): nu + sigma nu_t on the whole
+// ghosted plane, corners included
+__global__ void k_effective_diffusivity(Geo g, const double *nut, double nu, double sigma, double *out) {
+    const int ig = blockIdx.x * 64 + threadIdx.x, jg = blockIdx.y * 4 + threadIdx.y;
+    if (ig > g.ni + 1 || jg > g.nj + 1) return;
+    const size_t c = g.at(ig, jg);
+    out[c] = nu + sigma * nut[c];
+}
+
+int launch_effective_diffusivity(Ctx *c, double nu, double sigma, double *out) {
+    hipLaunchKernelGGL(k_effective_diffusivity, grid2d(c->g.ni + 2, c->g.nj + 2), block2d(), 0, c->stream, c->g, c->nut, nu, sigma, out);
+    CFD_HIP(hipGetLastError());
+    return CFD_OK;
+}
+
 // ----------------------------------------------------------------------------------
 // face diffusion conductances + momentum diagonal (solver.py:147-230, 439-452)
 // nu_cell = nu + coef * nu_t.  Writes a_i (west faces + the i_max face), a_j, a_P.

@@ -314,6 +314,20 @@ class Device:
     def eddy_viscosity(self):
         check(self.lib.cfd_eddy_viscosity(self._h))
 
+    def komega_sources(self, grad_u, grad_v):
+        """(source_k, source_omega) of the Wilcox closure from the k, omega, nu_t planes and the caller's gradients."""
+        gu, gv = _f64(grad_u), _f64(grad_v)
+        if gu.shape != (self.ni, self.nj, 2) or gv.shape != (self.ni, self.nj, 2):
+            raise ValueError(f"velocity gradients must be {(self.ni, self.nj, 2)} arrays")
+        sk, sw = np.empty((self.ni, self.nj)), np.empty((self.ni, self.nj))
+        check(self.lib.cfd_komega_sources(self._h, dptr(gu), dptr(gv), dptr(sk), dptr(sw)))
+        return sk, sw
+
+    def effective_diffusivity(self, nu, sigma):
+        out = np.empty((self.ni + 2, self.nj + 2))
+        check(self.lib.cfd_effective_diffusivity(self._h, float(nu), float(sigma), dptr(out)))
+        return out
+
     def momentum_diagonal(self, dt, nut_coef=1.0):
         check(self.lib.cfd_momentum_diagonal(self._h, float(dt), float(nut_coef)))
 
@@ -438,7 +452,7 @@ class Device:
 
     KERNEL_COUNT_NAMES = ("cheb4_2rhs", "cheb4_1rhs", "cheb2", "cheb1", "bicgstab_iters", "flux_march",
                           "flux_march_multistrip", "flux_tile", "mg_fused_levels_max", "mg_deferred_resid", "cg_pq",
-                          "vcycles", "mg_line_levels_max", "mg_tail_levels", "correct_flux")
+                          "vcycles", "mg_line_levels_max", "mg_tail_levels", "correct_flux", "mg_semi_levels")
 
     def kernel_counts(self, reset=False):
         """Launches per kernel family since the last reset (include/cfd_hip.h: cfd_kernel_counts)."""

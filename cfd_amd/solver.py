@@ -45,186 +45,210 @@ from .phases import (advect_scalar, apply_boundary_conditions, compute_adaptive_
 
 
 # ------------------------------------------------------------------ mesh / state IO
+# File names, array keys, log headers and the %.6e number format below are the contract with the reference's
+# files (solver.py:361-419 states, 1218-1293 logs, 1296-1364 save / restart); how they are produced is this
+# module's own: one ghosted-array helper for every state array, one row writer for the three logs, schedules
+# as sorted knot arrays.
+_STATE_META = ("step", "time", "cell_center")
+
+
+def _ghosted(mesh, interior=0.0):
+    """A (Ni+2, Nj+2) float array, zero ghosts, interior set from a scalar or an (Ni, Nj) array."""
+    arr = np.zeros((int(mesh["count_i"]) + 2, int(mesh["count_j"]) + 2), dtype=float)
+    arr[1:-1, 1:-1] = interior
+    return arr
+
+
+def _fill_ghosted(target, values):
+    """Stored arrays come ghosted or interior-only (load_state accepts both, solver.py:390-398)."""
+    values = np.asarray(values)
+    for view in (target, target[1:-1, 1:-1]):
+        if view.shape == values.shape:
+            view[...] = values
+            return
+    raise ValueError(f"Field shape {values.shape} does not match target {target.shape}.")
+
+
 def load_mesh(mesh_cfg):
-    """solver.py:361-367."""
-    mesh_path = Path(mesh_cfg["path"])
-    ensure_single_mesh_file(mesh_path)
-    if not mesh_path.exists():
+    """The mesh dict of mesh.precompute_from_nodes from its .npz, generated first when the file is absent."""
+    path = Path(mesh_cfg["path"])
+    ensure_single_mesh_file(path)
+    if not path.is_file():
         make_mesh(mesh_cfg)
-    with np.load(mesh_path, allow_pickle=False) as data:
-        return {key: data[key] for key in data.files}
+    with np.load(path, allow_pickle=False) as npz:
+        return dict(npz.items())
 
 
 def initialize_fields(mesh, initial_cfg):
-    """solver.py:370-387."""
-    count_i = int(mesh["count_i"])
-    count_j = int(mesh["count_j"])
-    shape = (count_i + 2, count_j + 2)
-    fields = {name: np.zeros(shape, dtype=float) for name in ("u", "v", "p")}
-    for name in ("u", "v", "p"):
-        fields[name][1:-1, 1:-1] = initial_cfg[name]
-    for name, value in initial_cfg.get("scalars", {}).items():
-        fields[name] = np.zeros(shape, dtype=float)
-        fields[name][1:-1, 1:-1] = value
-    return fields
-
-
-def _load_field_array(target, arr):
-    if arr.shape == target.shape:
-        target[:, :] = arr
-    elif arr.shape == target[1:-1, 1:-1].shape:
-        target[1:-1, 1:-1] = arr
-    else:
-        raise ValueError(f"Field shape {arr.shape} does not match target {target.shape}.")
+    """u, v, p and the named scalars of CONFIG["initial"] as ghosted arrays."""
+    wanted = {name: initial_cfg[name] for name in ("u", "v", "p")}
+    wanted.update(initial_cfg.get("scalars", {}))
+    return {name: _ghosted(mesh, value) for name, value in wanted.items()}
 
 
 def load_state(state_path, mesh, initial_cfg):
-    """solver.py:401-419."""
+    """(fields, step, time) of a saved state; arrays the initial config does not name are created on the fly."""
     fields = initialize_fields(mesh, initial_cfg)
-    with np.load(state_path, allow_pickle=False) as data:
-        for key in data.files:
-            if key in ("step", "time", "cell_center"):
-                continue
-            if key not in fields:
-                fields[key] = np.zeros_like(fields["p"])
-            _load_field_array(fields[key], data[key])
-        step = int(data["step"]) if "step" in data.files else None
-        time = float(data["time"]) if "time" in data.files else None
-    return fields, step, time
+    with np.load(state_path, allow_pickle=False) as npz:
+        stamp = {key: npz[key].item() for key in ("step", "time") if key in npz.files}
+        for name in npz.files:
+            if name not in _STATE_META:
+                _fill_ghosted(fields.setdefault(name, _ghosted(mesh)), npz[name])
+    return (fields, int(stamp["step"]) if "step" in stamp else None,
+            float(stamp["time"]) if "time" in stamp else None)
 
 
 def save_fields(mesh, fields, output_dir, step, time):
-    """solver.py:1296-1310."""
-    output_dir = Path(output_dir)
-    output_dir.mkdir(parents=True, exist_ok=True)
-    save_path = output_dir / f"fields_{step:06d}.npz"
-    payload = {"step": np.array(step, dtype=int), "time": np.array(time, dtype=float),
-               "cell_center": mesh["cell_center"]}
-    for key, value in fields.items():
-        if key != "p_corr":
-            payload[key] = value
-    np.savez(save_path, **payload)
-    return save_path
+    """states/fields_{step:06d}.npz: every entry of `fields` but p_corr, plus step, time, cell_center."""
+    folder = Path(output_dir)
+    folder.mkdir(parents=True, exist_ok=True)
+    target = folder / f"fields_{step:06d}.npz"
+    arrays = {name: arr for name, arr in fields.items() if name != "p_corr"}
+    np.savez(target, step=np.array(step, dtype=int), time=np.array(time, dtype=float),
+             cell_center=mesh["cell_center"], **arrays)
+    return target
 
 
-# ------------------------------------------------------------------ logs (formats: solver.py:1218-1293)
+# ------------------------------------------------------------------ logs
+_LOG_COLUMNS = {
+    "residual": "step time inner_iter continuity_l2 mom_u_l2 mom_v_l2",
+    "timing": "step time inner_iter total bc adv mom press corr cont turb post save",
+    "friction": "step time f_darcy f_darcy_dpdx tau_avg u_bulk reynolds",
+}
+
+
+def _log_file(post_dir, case_name, kind):
+    return Path(post_dir) / f"{case_name}_{kind}_log.txt"
+
+
+def _append_row(post_dir, case_name, kind, step, time, counters, numbers):
+    """One line of a log: step, time, integer columns as they are, float columns in the reference's %.6e;
+    the header goes in front of the first line of a new file."""
+    path = _log_file(post_dir, case_name, kind)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    cells = [str(step), f"{time:.6e}", *(str(v) for v in counters), *(f"{float(v):.6e}" for v in numbers)]
+    text = " ".join(cells) + "\n"
+    if not path.exists():
+        text = _LOG_COLUMNS[kind] + "\n" + text
+    with path.open("a", encoding="utf-8") as handle:
+        handle.write(text)
+    return path
+
+
 def log_residual(post_dir, case_name, step, time, inner_iter, residual, mom_u_l2, mom_v_l2):
-    post_dir.mkdir(parents=True, exist_ok=True)
-    log_path = post_dir / f"{case_name}_residual_log.txt"
-    if not log_path.exists():
-        log_path.write_text("step time inner_iter continuity_l2 mom_u_l2 mom_v_l2\n")
-    with log_path.open("a", encoding="utf-8") as handle:
-        handle.write(f"{step} {time:.6e} {inner_iter} {residual:.6e} {mom_u_l2:.6e} {mom_v_l2:.6e}\n")
-    return log_path
+    return _append_row(post_dir, case_name, "residual", step, time, (inner_iter,), (residual, mom_u_l2, mom_v_l2))
 
 
 def log_timing(post_dir, case_name, step, time, inner_iter, timing):
-    post_dir.mkdir(parents=True, exist_ok=True)
-    log_path = post_dir / f"{case_name}_timing_log.txt"
-    if not log_path.exists():
-        log_path.write_text("step time inner_iter total bc adv mom press corr cont turb post save\n")
-    keys = ("total", "bc", "adv", "mom", "press", "corr", "cont", "turb", "post", "save")
-    with log_path.open("a", encoding="utf-8") as handle:
-        handle.write(f"{step} {time:.6e} {inner_iter} " + " ".join(f"{timing[k]:.6e}" for k in keys) + "\n")
-    return log_path
+    phases = _LOG_COLUMNS["timing"].split()[3:]
+    return _append_row(post_dir, case_name, "timing", step, time, (inner_iter,), [timing[name] for name in phases])
 
 
 def log_friction(post_dir, case_name, step, time, cf, tau_avg, bulk_velocity=None, re=None, cf_dpdx=None):
-    post_dir.mkdir(parents=True, exist_ok=True)
-    log_path = post_dir / f"{case_name}_friction_log.txt"
-    if not log_path.exists():
-        log_path.write_text("step time f_darcy f_darcy_dpdx tau_avg u_bulk reynolds\n")
-    nan = float("nan")
-    bulk_velocity = nan if bulk_velocity is None else bulk_velocity
-    re = nan if re is None else re
-    cf_dpdx = nan if cf_dpdx is None else cf_dpdx
-    with log_path.open("a", encoding="utf-8") as handle:
-        handle.write(f"{step} {time:.6e} {4.0 * float(cf):.6e} {4.0 * float(cf_dpdx):.6e} "
-                     f"{tau_avg:.6e} {bulk_velocity:.6e} {re:.6e}\n")
-    return log_path
+    """Darcy friction factors are four times the Fanning coefficients the diagnostic returns."""
+    absent = float("nan")
+    optional = [absent if v is None else v for v in (bulk_velocity, re)]
+    darcy_dpdx = absent if cf_dpdx is None else 4.0 * float(cf_dpdx)
+    return _append_row(post_dir, case_name, "friction", step, time, (), (4.0 * float(cf), darcy_dpdx, tau_avg, *optional))
 
 
-def _ensure_single_log_file(post_dir, log_path):
-    if not post_dir.exists():
+def _only_residual_log(post_dir, log_path):
+    """A postproc directory holds the residual log of ONE case (the plotting code globs for it)."""
+    post_dir = Path(post_dir)
+    if not post_dir.is_dir():
         return
-    others = [p for p in sorted(post_dir.glob("*_residual_log.txt")) if p.resolve() != log_path.resolve()]
-    if others:
-        names = ", ".join(p.name for p in others)
-        raise ValueError(f"Multiple residual logs found in {post_dir}: {names}. Remove extras.")
+    mine = Path(log_path).resolve()
+    strays = sorted(p.name for p in post_dir.glob("*_residual_log.txt") if p.resolve() != mine)
+    if strays:
+        raise ValueError(f"Multiple residual logs found in {post_dir}: {', '.join(strays)}. Remove extras.")
 
 
-def _truncate_log(post_dir, case_name, restart_step):
-    """solver.py:1330-1354."""
-    log_path = post_dir / f"{case_name}_residual_log.txt"
-    if not log_path.exists():
-        return
-    lines = log_path.read_text().splitlines()
-    if not lines:
-        return
-    kept = [lines[0]]
-    for line in lines[1:]:
-        parts = line.split()
-        if not parts:
-            continue
+def _rows_before(rows, first_dropped_step):
+    """The leading rows whose step number lies below the restart step; rows without a number are skipped."""
+    for row in rows:
         try:
-            step = int(float(parts[0]))
-        except ValueError:
+            number = int(float(row.split(None, 1)[0]))
+        except (IndexError, ValueError):
             continue
-        if step < restart_step:
-            kept.append(line)
-        else:
-            break
-    log_path.write_text("\n".join(kept) + "\n")
+        if number >= first_dropped_step:
+            return
+        yield row
 
 
-def _resolve_restart_state(config, states_dir):
-    restart_cfg = config.get("restart", {})
-    if not restart_cfg.get("enabled", False):
+def _cut_log_at(post_dir, case_name, restart_step):
+    """A restart continues the residual log from `restart_step`: what was logged from there on goes."""
+    path = _log_file(post_dir, case_name, "residual")
+    rows = path.read_text().splitlines() if path.exists() else []
+    if rows:
+        path.write_text("\n".join([rows[0], *_rows_before(rows[1:], restart_step)]) + "\n")
+
+
+def _restart_source(config, states_dir):
+    """Path of the state a restart starts from: restart.path, or the fields file of restart.step; None: fresh run."""
+    restart = config.get("restart") or {}
+    if not restart.get("enabled", False):
         return None
-    if restart_cfg.get("path"):
-        return Path(restart_cfg["path"])
-    if restart_cfg.get("step") is None:
+    explicit, from_step = restart.get("path"), restart.get("step")
+    if explicit:
+        return Path(explicit)
+    if from_step is None:
         raise ValueError("restart enabled but no path or step provided")
-    return Path(states_dir) / f"fields_{int(restart_cfg['step']):06d}.npz"
+    return Path(states_dir) / f"fields_{int(from_step):06d}.npz"
 
 
-def _resolve_case_paths(config, mesh_path):
-    paths = config.get("paths", {})
-    case_dir = Path(paths.get("case_dir", mesh_path.parent.parent))
-    return (case_dir, Path(paths.get("mesh_dir", case_dir / "mesh")),
-            Path(paths.get("states_dir", case_dir / "states")), Path(paths.get("post_dir", case_dir / "postproc")))
+def _case_directories(config, mesh_path):
+    """(case, mesh, states, postproc) directories; the case directory defaults to two levels above the mesh file."""
+    given = config.get("paths", {})
+    case_dir = Path(given.get("case_dir", Path(mesh_path).parent.parent))
+    sub = {"mesh_dir": "mesh", "states_dir": "states", "post_dir": "postproc"}
+    return (case_dir, *(Path(given.get(key, case_dir / name)) for key, name in sub.items()))
 
 
-# ------------------------------------------------------------------ schedules (solver.py:613-646)
-def _parse_value_schedule(schedule, name):
-    if schedule is None:
-        return None
-    items = []
-    for entry in schedule:
-        if len(entry) != 2:
-            raise ValueError(f"{name} entries must be (value, step).")
-        items.append((float(entry[0]), int(entry[1])))
-    items.sort(key=lambda x: x[1])
-    steps = [s for _, s in items]
-    if any(s < 0 for s in steps):
-        raise ValueError(f"{name} steps must be non-negative.")
-    if any(b <= a for a, b in zip(steps, steps[1:])):
-        raise ValueError(f"{name} steps must be strictly increasing.")
-    return items
+# ------------------------------------------------------------------ schedules
+class Schedule:
+    """(value, step) knots of a CONFIG schedule (cfl_schedule, dt_max_schedule, piso.corrector_schedule, ...):
+    piecewise linear in the step number, held at the end values outside the knots.  Compares equal to the sorted
+    list of (value, step) pairs."""
+
+    def __init__(self, entries, name):
+        pairs = []
+        for entry in entries:
+            if len(entry) != 2:
+                raise ValueError(f"{name} entries must be (value, step).")
+            pairs.append((int(entry[1]), float(entry[0])))
+        pairs.sort()
+        self.steps = np.array([p[0] for p in pairs], dtype=np.int64)
+        self.values = np.array([p[1] for p in pairs], dtype=float)
+        if (self.steps < 0).any():
+            raise ValueError(f"{name} steps must be non-negative.")
+        if (np.diff(self.steps) <= 0).any():
+            raise ValueError(f"{name} steps must be strictly increasing.")
+
+    def __call__(self, step):
+        hi = int(np.searchsorted(self.steps, step, side="left"))       # first knot at or after `step`
+        if hi == 0 or hi == self.steps.size:
+            return float(self.values[min(hi, self.steps.size - 1)])
+        lo = hi - 1
+        t = (step - int(self.steps[lo])) / float(int(self.steps[hi]) - int(self.steps[lo]))
+        # the reference's blend, term by term, so that a scheduled cfl has the reference's bits (solver.py:632-646)
+        return (1.0 - t) * float(self.values[lo]) + t * float(self.values[hi])
+
+    def pairs(self):
+        return [(float(v), int(s)) for s, v in zip(self.steps, self.values)]
+
+    def __eq__(self, other):
+        return self.pairs() == (other.pairs() if isinstance(other, Schedule) else other)
+
+    def __len__(self):
+        return int(self.steps.size)
 
 
-def _scheduled_value(step, base_value, schedule):
-    if not schedule:
-        return base_value
-    if step <= schedule[0][1]:
-        return schedule[0][0]
-    for (val_a, step_a), (val_b, step_b) in zip(schedule[:-1], schedule[1:]):
-        if step <= step_b:
-            if step_b == step_a:
-                return val_b
-            t = (step - step_a) / float(step_b - step_a)
-            return (1.0 - t) * val_a + t * val_b
-    return schedule[-1][0]
+def _schedule_of(schedule, name):
+    return None if schedule is None else Schedule(schedule, name)
+
+
+def _value_at(step, base_value, schedule):
+    return schedule(step) if schedule is not None and len(schedule) else base_value
 
 
 # ------------------------------------------------------------------ turbulence helpers
@@ -310,11 +334,11 @@ class StepControl:
         self.dt = time_cfg.get("dt")
         self.max_steps = time_cfg["max_steps"]
         self.cfl = time_cfg.get("cfl")
-        self.cfl_schedule = _parse_value_schedule(time_cfg.get("cfl_schedule"), "cfl_schedule")
+        self.cfl_schedule = _schedule_of(time_cfg.get("cfl_schedule"), "cfl_schedule")
         self.cfl_diff = time_cfg.get("cfl_diff")
-        self.cfl_diff_schedule = _parse_value_schedule(time_cfg.get("cfl_diff_schedule"), "cfl_diff_schedule")
+        self.cfl_diff_schedule = _schedule_of(time_cfg.get("cfl_diff_schedule"), "cfl_diff_schedule")
         self.dt_max = time_cfg.get("dt_max", self.dt)
-        self.dt_max_schedule = _parse_value_schedule(time_cfg.get("dt_max_schedule"), "dt_max_schedule")
+        self.dt_max_schedule = _schedule_of(time_cfg.get("dt_max_schedule"), "dt_max_schedule")
         self.dt_min = time_cfg.get("dt_min", 0.0)
         if self.cfl is None and self.cfl_schedule is None and self.dt is None:
             raise ValueError("time.dt must be provided when time.cfl is not set.")
@@ -330,7 +354,7 @@ class StepControl:
         self.relax_p = simple_cfg.get("relax_p", 0.3)
         piso_cfg = solver_cfg.get("piso", {})
         self.piso_correctors = int(piso_cfg.get("n_correctors", 3))
-        self.piso_schedule = _parse_value_schedule(piso_cfg.get("corrector_schedule"), "piso.corrector_schedule")
+        self.piso_schedule = _schedule_of(piso_cfg.get("corrector_schedule"), "piso.corrector_schedule")
         self.piso_relax_u = piso_cfg.get("relax_u", self.relax_u)
         self.piso_relax_v = piso_cfg.get("relax_v", self.relax_v)
         self.piso_relax_p = piso_cfg.get("relax_p", self.relax_p)
@@ -344,9 +368,9 @@ def advance_one_step(dev, ctl, step):
     Returns dict(dt, dt_adv, dt_diff, inner, cont, mom_u, mom_v, step_cfl, step_cfl_diff, step_dt_max)
     or None when the adaptive dt collapsed to <= 0 (solver.py:1487-1488)."""
     dev.apply_flow_bc()
-    step_cfl = _scheduled_value(step, ctl.cfl, ctl.cfl_schedule)
-    step_cfl_diff = _scheduled_value(step, ctl.cfl_diff, ctl.cfl_diff_schedule)
-    step_dt_max = _scheduled_value(step, ctl.dt_max, ctl.dt_max_schedule)
+    step_cfl = _value_at(step, ctl.cfl, ctl.cfl_schedule)
+    step_cfl_diff = _value_at(step, ctl.cfl_diff, ctl.cfl_diff_schedule)
+    step_dt_max = _value_at(step, ctl.dt_max, ctl.dt_max_schedule)
     dt_adv = dt_diff = None
     if step_cfl is not None:
         if step_cfl_diff is None:
@@ -362,7 +386,7 @@ def advance_one_step(dev, ctl, step):
     if ctl.scheme == "piso":
         n_corr = ctl.piso_correctors
         if ctl.piso_schedule is not None:
-            n_corr = int(_scheduled_value(step, ctl.piso_correctors, ctl.piso_schedule))
+            n_corr = int(_value_at(step, ctl.piso_correctors, ctl.piso_schedule))
         n_corr = max(1, n_corr)
         cont, mom_u, mom_v = dev.piso_step(dt, n_corr, ctl.piso_relax_u, ctl.piso_relax_v, ctl.piso_relax_p)
         inner = n_corr
@@ -392,72 +416,109 @@ LAST_RUN = {}
 
 
 # ------------------------------------------------------------------ run_case
+_CONSOLE_LINE = ("step {step} time {time:.6e} dt_min {dt:.3e} dt_max {dt:.3e} dt_lim {limit} wall {wall:.2f}s "
+                 "scheme {scheme} inner {inner} cont {cont:.6e} mom_u {mom_u:.6e} mom_v {mom_v:.6e}")      # solver.py:1752-1770
+_TIMED_PHASES = ("bc", "adv", "mom", "press", "corr", "cont", "turb")
+
+
+class OutputControl:
+    """What a run writes and how often: CONFIG["post"], CONFIG["paths"], CONFIG["case_name"] (solver.py:1416-1431)."""
+
+    def __init__(self, config, mesh_path):
+        post = config.get("post", {})
+        self.save_every = post.get("save_interval", 0)
+        shown = post.get("print_interval", 1)
+        self.print_every = 1 if shown is None else int(shown)
+        self.residual_every = int(post.get("residual_log_interval", 1))
+        self.friction_every = int(post.get("friction_log_interval", 1))
+        self.timing = bool(post.get("timing", {}).get("enabled", False))
+        self.friction = post.get("friction", {})
+        self.friction_on = bool(self.friction.get("enabled", False))
+        self.case = config.get("case_name", Path(mesh_path).stem)
+        _, _, self.states_dir, self.post_dir = _case_directories(config, mesh_path)
+        self.residual_log = _log_file(self.post_dir, self.case, "residual")
+
+    @staticmethod
+    def due(step, every):
+        """Log cadence: every step for an interval of 0 or 1, else the steps the interval divides."""
+        return every <= 1 or step % every == 0
+
+    def prints(self, step):
+        return self.print_every == 0 or step % self.print_every == 0
+
+    def saves(self, step):
+        return bool(self.save_every) and step % self.save_every == 0
+
+
+def _dt_limit_label(info, dt, dt_min):
+    """Which bound set the step's dt, for the console line: adv | diff | max | min | fixed."""
+    adv, diff = info["dt_adv"], info["dt_diff"]
+    if adv is None or diff is None:
+        return "fixed"
+    label = "adv" if adv <= diff else "diff"
+    if info["step_dt_max"] is not None and np.isclose(dt, float(info["step_dt_max"])):
+        label = "max"
+    if dt_min is not None and np.isclose(dt, float(dt_min)):
+        label = "min"
+    return label
+
+
+def _starting_state(config, mesh, ctl, out, writer):
+    """(fields, step, time) a run starts from: a saved state (the residual log is cut back to it) or CONFIG["initial"]
+    (an older residual log of the case is removed).  solver.py:1433-1447."""
+    source = _restart_source(config, out.states_dir)
+    if source is None:
+        if writer and out.residual_log.exists():
+            out.residual_log.unlink()
+        return initialize_fields(mesh, config["initial"]), 0, 0.0
+    fields, step, time = load_state(source, mesh, config["initial"])
+    if step is None:
+        step = int((config.get("restart") or {}).get("step", 0) or 0)
+    if time is None:
+        per_step = ctl.dt_max if ctl.dt_max is not None else (ctl.dt or 0.0)
+        time = step * per_step
+    if writer:
+        _cut_log_at(out.post_dir, out.case, step)
+    return fields, step, time
+
+
 def run_case(config):
     """Run a case configuration through the SIMPLE / PISO loop on the GPU
     (solver.run_case, solver.py:1367-1800).  Returns (fields, step, time)."""
     solver_cfg = config.get("solver", {})
-    mesh_cfg = config["mesh"]
-    mesh_path = Path(mesh_cfg["path"])
-    mesh = load_mesh(mesh_cfg)
+    mesh = load_mesh(config["mesh"])
     ctl = StepControl(config)
     if ctl.scheme not in ("simple", "piso"):
         ctl.scheme = "simple"        # the reference treats anything but "piso" as SIMPLE (solver.py:1494, 1590)
     nu = config["physics"]["nu"]
-    post_cfg = config.get("post", {})
-    save_interval = post_cfg.get("save_interval", 0)
-    print_interval = post_cfg.get("print_interval", 1)
-    residual_log_interval = int(post_cfg.get("residual_log_interval", 1))
-    friction_log_interval = int(post_cfg.get("friction_log_interval", 1))
-    timing_cfg = post_cfg.get("timing", {})
-    timing_enabled = bool(timing_cfg.get("enabled", False))
-    friction_cfg = post_cfg.get("friction", {})
-    friction_enabled = bool(friction_cfg.get("enabled", False))
-
-    case_name = config.get("case_name", mesh_path.stem)
-    _, _, states_dir, post_dir = _resolve_case_paths(config, mesh_path)
-    states_dir.mkdir(parents=True, exist_ok=True)
-    post_dir.mkdir(parents=True, exist_ok=True)
-    log_path = post_dir / f"{case_name}_residual_log.txt"
+    out = OutputControl(config, config["mesh"]["path"])
+    for folder in (out.states_dir, out.post_dir):
+        folder.mkdir(parents=True, exist_ok=True)
+    slabs = _distributed_world() > 1
     writer = True                      # only rank 0 of a j-slab job touches the log files
-    if _distributed_world() > 1:
+    if slabs:
         import torch.distributed as dist
         writer = dist.get_rank() == 0
     if writer:
-        _ensure_single_log_file(post_dir, log_path)
-
-    restart_path = _resolve_restart_state(config, states_dir)
-    if restart_path:
-        fields, step, time = load_state(restart_path, mesh, config["initial"])
-        if step is None:
-            step = int(config.get("restart", {}).get("step", 0) or 0)
-        if time is None:
-            dt_ref = ctl.dt_max if ctl.dt_max is not None else (ctl.dt or 0.0)
-            time = step * dt_ref
-        if writer:
-            _truncate_log(post_dir, case_name, step)
-    else:
-        fields = initialize_fields(mesh, config["initial"])
-        time = 0.0
-        step = 0
-        if writer and log_path.exists():
-            log_path.unlink()
+        _only_residual_log(out.post_dir, out.residual_log)
+    fields, step, time = _starting_state(config, mesh, ctl, out, writer)
 
     turb_cfg = config.get("turbulence", {})
     turb_on = ctl.turb_on
     _validate_turbulence(fields, turb_cfg, config["boundary"])
-    count_i, count_j = int(mesh["count_i"]), int(mesh["count_j"])
     if "nu_t" not in fields:
-        fields["nu_t"] = np.zeros((count_i + 2, count_j + 2), dtype=float)
+        fields["nu_t"] = _ghosted(mesh)
     elif not turb_on:
-        fields["nu_t"][:, :] = 0.0
+        fields["nu_t"][...] = 0.0
+    count_i, count_j = fields["u"].shape[0] - 2, fields["u"].shape[1] - 2
 
     # under an initialised torch.distributed job every rank calls run_case with the same CONFIG
     # and owns one j-slab; rank 0 writes the logs and states, every rank returns the whole fields
-    if _distributed_world() > 1:
+    if slabs:
         from .slab import slab_device
-        dev = slab_device(count_i, count_j, default_device_ordinal(solver_cfg),
-                          min_slab_rows=solver_cfg.get("slab", {}).get("min_rows"),
-                          transport=solver_cfg.get("slab", {}).get("transport"))
+        slab_cfg = solver_cfg.get("slab", {})
+        dev = slab_device(count_i, count_j, default_device_ordinal(solver_cfg), min_slab_rows=slab_cfg.get("min_rows"),
+                          transport=slab_cfg.get("transport"))
     else:
         dev = Device(count_i, count_j, default_device_ordinal(solver_cfg))
     root = dev.rank == 0
@@ -467,79 +528,58 @@ def run_case(config):
         if turb_on:
             dev.set_turbulence_model(turb_cfg.get("model"), mesh, config["boundary"])
         dev.upload_fields(fields)
-        if timing_enabled:
-            dev.enable_phase_timing(True)
-        fields["p_corr"] = np.zeros((count_i + 2, count_j + 2), dtype=float)
+        dev.enable_phase_timing(out.timing)
+        fields["p_corr"] = _ghosted(mesh)
 
-        step_end = step + ctl.max_steps
-        start_wall_time = time_module.perf_counter()
+        last_step = step + ctl.max_steps
+        run_started = time_module.perf_counter()
         host_fresh = False
         wall = None
-        while step < step_end:
-            step_start = time_module.perf_counter()
-            timing = dict.fromkeys(("total", "bc", "adv", "mom", "press", "corr", "cont", "turb", "post", "save"), 0.0)
+        while step < last_step:
+            step_started = time_module.perf_counter()
             info = advance_one_step(dev, ctl, step)
             if info is None:
                 break
             host_fresh = False
-            dt, inner_iter, cont_res = info["dt"], info["inner"], info["cont"]
-            mom_u_l2, mom_v_l2 = info["mom_u"], info["mom_v"]
-            if timing_enabled:
-                ph = dev.phase_times(reset=True)
-                for key in ("bc", "adv", "mom", "press", "corr", "cont", "turb"):
-                    timing[key] = ph[key]
+            dt, cont = info["dt"], info["cont"]
+            spent = dict.fromkeys(_LOG_COLUMNS["timing"].split()[3:], 0.0)
+            if out.timing:
+                device_times = dev.phase_times(reset=True)
+                spent.update({name: device_times[name] for name in _TIMED_PHASES})
 
-            if root and cont_res is not None and (residual_log_interval <= 1 or step % residual_log_interval == 0):
-                log_residual(post_dir, case_name, step, time, inner_iter, cont_res, mom_u_l2, mom_v_l2)
-            if friction_enabled and (friction_log_interval <= 1 or step % friction_log_interval == 0):
+            if root and cont is not None and out.due(step, out.residual_every):
+                log_residual(out.post_dir, out.case, step, time, info["inner"], cont, info["mom_u"], info["mom_v"])
+            if out.friction_on and out.due(step, out.friction_every):
                 # edge kernel + device reductions: nothing but a few scalars crosses PCIe (cfd_wall_friction)
+                fr = out.friction
                 if wall is None:
-                    wall = post_processing.WallFriction(mesh, friction_cfg.get("boundary", "j_min"),
-                                                        friction_cfg.get("range"))
+                    wall = post_processing.WallFriction(mesh, fr.get("boundary", "j_min"), fr.get("range"))
                 friction = post_processing.friction_coefficient_device(
-                    dev, wall, nu=config["physics"]["nu"], rho=friction_cfg.get("rho", 1.0),
-                    u_ref=friction_cfg.get("u_ref"), use_nu_t=bool(friction_cfg.get("use_nu_t", False)),
-                    flow_axis=friction_cfg.get("flow_axis", "i"),
-                    hydraulic_diameter=friction_cfg.get("hydraulic_diameter"),
+                    dev, wall, nu=nu, rho=fr.get("rho", 1.0), u_ref=fr.get("u_ref"), use_nu_t=bool(fr.get("use_nu_t", False)),
+                    flow_axis=fr.get("flow_axis", "i"), hydraulic_diameter=fr.get("hydraulic_diameter"),
                     pressure_gradient=config["physics"].get("pressure_gradient"))
                 if root:
-                    log_friction(post_dir, case_name, step, time, friction["cf"], friction["tau_avg"],
+                    log_friction(out.post_dir, out.case, step, time, friction["cf"], friction["tau_avg"],
                                  bulk_velocity=friction.get("bulk_velocity"), re=friction.get("re"),
                                  cf_dpdx=friction.get("cf_dpdx"))
 
-            elapsed = time_module.perf_counter() - start_wall_time
-            if print_interval is None:
-                print_interval = 1
-            if root and (print_interval == 0 or step % int(print_interval) == 0):
-                adv_min, diff_min = info["dt_adv"], info["dt_diff"]
-                dt_limit = "fixed"
-                if adv_min is not None and diff_min is not None:
-                    dt_limit = "adv" if adv_min <= diff_min else "diff"
-                    if info["step_dt_max"] is not None and np.isclose(dt, float(info["step_dt_max"])):
-                        dt_limit = "max"
-                    if ctl.dt_min is not None and np.isclose(dt, float(ctl.dt_min)):
-                        dt_limit = "min"
-                resid_value = cont_res if cont_res is not None else float("nan")
-                print(
-                    "step {step} time {time:.6e} dt_min {dt_min:.3e} dt_max {dt_max:.3e} "
-                    "dt_lim {dt_lim} wall {elapsed:.2f}s "
-                    "scheme {scheme} inner {inner} cont {resid:.6e} mom_u {mom_u:.6e} mom_v {mom_v:.6e}".format(
-                        step=step, time=time, dt_min=dt, dt_max=dt, dt_lim=dt_limit, elapsed=elapsed,
-                        scheme=ctl.scheme, inner=inner_iter, resid=resid_value, mom_u=mom_u_l2, mom_v=mom_v_l2),
-                    flush=True)
-            if save_interval and step % save_interval == 0:
-                t0 = time_module.perf_counter()
+            if root and out.prints(step):
+                print(_CONSOLE_LINE.format(step=step, time=time, dt=dt, limit=_dt_limit_label(info, dt, ctl.dt_min),
+                                           wall=time_module.perf_counter() - run_started, scheme=ctl.scheme,
+                                           inner=info["inner"], cont=float("nan") if cont is None else cont,
+                                           mom_u=info["mom_u"], mom_v=info["mom_v"]), flush=True)
+            if out.saves(step):
+                save_started = time_module.perf_counter()
                 if not host_fresh:
                     dev.download_fields(fields)
                     host_fresh = True
                 if root:
-                    save_path = save_fields(mesh, fields, states_dir, step, time)
-                    print(f"saved {save_path}", flush=True)
-                timing["save"] += time_module.perf_counter() - t0
+                    print(f"saved {save_fields(mesh, fields, out.states_dir, step, time)}", flush=True)
+                spent["save"] += time_module.perf_counter() - save_started
 
-            timing["total"] = time_module.perf_counter() - step_start
-            if timing_enabled and root:
-                log_timing(post_dir, case_name, step, time, inner_iter, timing)
+            spent["total"] = time_module.perf_counter() - step_started
+            if out.timing and root:
+                log_timing(out.post_dir, out.case, step, time, info["inner"], spent)
             time += dt
             step += 1
 

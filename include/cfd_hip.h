@@ -329,6 +329,12 @@ int cfd_bulk_velocity_noalloc(const double *field_dev, const double *volume_dev,
 /* ---- fine-grained entry points (parity tests; README.md:196-205 function list) ------- */
 /* turbulence.eddy_viscosity, k-omega branch (turbulence.py:388-394): nu_t plane from k, omega */
 int cfd_eddy_viscosity(cfd_ctx *ctx);
+/* turbulence._sources_komega (turbulence.py:427-444) from the k, omega, nu_t planes and the CALLER'S velocity
+ * gradients grad_u, grad_v (host (Ni, Nj, 2), as solver.grad_scalar returns them): source_k, source_omega host (Ni, Nj) */
+int cfd_komega_sources(cfd_ctx *ctx, const double *grad_u, const double *grad_v, double *source_k, double *source_omega);
+/* turbulence.effective_diffusivity, constant-sigma branch (turbulence.py:568-577): nu + sigma * nu_t of the nu_t plane,
+ * host (Ni+2, Nj+2), corners included                                                                            */
+int cfd_effective_diffusivity(cfd_ctx *ctx, double nu, double sigma, double *out);
 /* solver._diffusion_coefficients + _momentum_diagonal (solver.py:147-230, 439-452):
  * writes a_i, a_j, a_P planes for nu_eff = nu + nut_coef * nu_t                           */
 int cfd_momentum_diagonal(cfd_ctx *ctx, double dt, double nut_coef);

@@ -130,20 +130,20 @@ def test_bc_validation_errors_match_reference():
 
 def test_schedules_and_logs(tmp_path):
     from cfd_amd import solver
-    sched = solver._parse_value_schedule([(0.4, 4), (0.2, 0)], "cfl_schedule")
+    sched = solver._schedule_of([(0.4, 4), (0.2, 0)], "cfl_schedule")
     assert sched == [(0.2, 0), (0.4, 4)]
-    assert solver._scheduled_value(0, 9.0, sched) == 0.2
-    assert solver._scheduled_value(2, 9.0, sched) == pytest.approx(0.3)
-    assert solver._scheduled_value(99, 9.0, sched) == 0.4
-    assert solver._scheduled_value(3, 9.0, None) == 9.0
+    assert solver._value_at(0, 9.0, sched) == 0.2
+    assert solver._value_at(2, 9.0, sched) == pytest.approx(0.3)
+    assert solver._value_at(99, 9.0, sched) == 0.4
+    assert solver._value_at(3, 9.0, None) == 9.0
     with pytest.raises(ValueError):
-        solver._parse_value_schedule([(1.0, 3), (2.0, 3)], "x")
+        solver._schedule_of([(1.0, 3), (2.0, 3)], "x")
     p = solver.log_residual(tmp_path, "c", 10, 1.5e-3, 2, 9.251522e-4, 1e-12, 2e-13)
     solver.log_residual(tmp_path, "c", 20, 3.0e-3, 2, 1.0e-4, 1e-12, 2e-13)
     lines = p.read_text().splitlines()
     assert lines[0] == "step time inner_iter continuity_l2 mom_u_l2 mom_v_l2"
     assert lines[1] == "10 1.500000e-03 2 9.251522e-04 1.000000e-12 2.000000e-13"
-    solver._truncate_log(tmp_path, "c", 20)
+    solver._cut_log_at(tmp_path, "c", 20)
     assert len(p.read_text().splitlines()) == 2
     f = solver.log_friction(tmp_path, "c", 0, 0.0, 0.01, 0.5, bulk_velocity=0.8, re=1e4, cf_dpdx=0.02)
     assert f.read_text().splitlines()[1] == "0 0.000000e+00 4.000000e-02 8.000000e-02 5.000000e-01 8.000000e-01 1.000000e+04"
