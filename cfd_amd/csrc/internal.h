@@ -226,8 +226,9 @@ struct SemiLevel {
     Geo g;
     double *ci, *cj, *D;          // operator (level 0: the planes of the finest pressure level)
     double *x, *b;                // levels >= 1
-    double *lm, *linv, *le;       // Thomas factors of the whole i-lines: multiplier, inverse pivot, c_E / pivot
-    double *z, *rs;               // periodic lines (Sherman-Morrison): T'^-1 u per cell; per row {beta / gamma, 1 / (1 + v.z)}
+    float *lmf, *linvf, *cjf;     // single precision: Thomas factors of the whole i-lines (multiplier, inverse pivot), c_j
+    float *zf;                    // periodic lines (Sherman-Morrison): T'^-1 u per cell (null: lines are not periodic)
+    double *rs;                   // ... and per row {beta / gamma, 1 / (1 + v . z)}
 };
 
 // V-cycle tail: the levels small enough to live in the LDS of one workgroup are cycled by ONE launch (k_mg_tail)
