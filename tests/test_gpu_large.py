@@ -247,6 +247,55 @@ def test_multistrip_kernels_against_reference_vectors(tag, marching):
 # ---------------------------------------------------------------------------------------------------------------------
 # stretched meshes: alternating line smoother (the reference's real cases are wall-graded, Runs/*/config.py ratio_j 1.03)
 # ---------------------------------------------------------------------------------------------------------------------
+SEMI_CASES = {
+    # tag: (mesh, boundary, periodic i, most MG-PCG iterations at rtol 1e-8 with the semi-coarsened line multigrid)
+    "channel_128_r1.04": lambda: (orc.rect_mesh(1.0, 1.0, 128, 128, 1.0, 1.04), "per_i", True, 14),
+    "channel_256_Lx4": lambda: (orc.rect_mesh(4.0, 1.0, 256, 256, 1.0, 1.0118), "per_i", True, 13),
+    "annulus_132x24": lambda: (orc.annulus_mesh(0.5, 6.0, 132, 24, 0.0, float(np.pi), 1.02, 1.0), "cyl", False, 8),
+    "annulus_512x256": lambda: (orc.annulus_mesh(0.5, 20.0, 512, 256, 0.0, float(np.pi), 1.012, 1.0), "cyl", False, 9),
+    "inout_300x128": lambda: (orc.rect_mesh(2.0, 1.0, 300, 128, 1.0, 1.02), "inout", False, 11),
+    "channel_1100x96_r1.05": lambda: (orc.rect_mesh(3.0, 1.0, 1100, 96, 1.0, 1.05), "per_i", True, 12),
+    "channel_2200x64_r1.08": lambda: (orc.rect_mesh(3.0, 1.0, 2200, 64, 1.0, 1.08), "per_i", True, 10),
+    "channel_4200x32_r1.1": lambda: (orc.rect_mesh(6.0, 1.0, 4200, 32, 1.0, 1.1), "per_i", True, 10),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(SEMI_CASES))
+def test_semi_coarsened_line_multigrid(tag):
+    """Stretched meshes are cycled by zebra whole-line relaxation along i + semi-coarsening along j (csrc/semi.inc):
+    lines of 128 .. 4200 cells (one to eight cells per thread, 4 and 16 waves per line, periodic and not), the solution
+    of the double-precision system (true residual from the scipy matrix), a symmetric preconditioner (PCG, and
+    (r1, B r2) = (B r1, r2)), no more iterations than the alternating block line smoother it replaces."""
+    from test_gpu_parity import _bc_variant, _device_for
+    mesh, kind, per_i, bound = SEMI_CASES[tag]()
+    ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
+    bc = cases._half_cylinder_bc(ni, nj, False) if kind == "cyl" else _bc_variant(kind, ni, nj)
+    res = {}
+    for semi in (1, 0):
+        dev = _device_for(mesh, bc, 1e-3, turbulent=False)
+        dev.set_option("mg_semi", semi)
+        dev.upload_fields({k: np.zeros((ni + 2, nj + 2)) for k in ("u", "v", "p", "nu_t")})
+        dev.momentum_diagonal(3e-3, 1.0)
+        ci, cj, diag, _ = dev.pressure_system()
+        a = orc.five_point_matrix(diag, ci[:-1], ci[1:], cj[:, :-1], cj[:, 1:], per_i, False)
+        rng = np.random.default_rng(1)
+        x_true = rng.standard_normal((ni, nj))
+        b = a.dot(x_true.ravel()).reshape(ni, nj)
+        sol, iters, relres = dev.pressure_krylov(b, tol=1e-8, maxiter=400)
+        true_res = np.linalg.norm(a.dot(sol.ravel()) - b.ravel()) / np.linalg.norm(b.ravel())
+        if semi:
+            r1, r2 = rng.standard_normal((ni, nj)), rng.standard_normal((ni, nj))
+            z1, z2 = dev.vcycle(r1), dev.vcycle(r2)
+            sym = abs(np.vdot(r1, z2) - np.vdot(z1, r2)) / abs(np.vdot(r1, z2))
+            assert np.vdot(r1, z1) > 0.0 and np.vdot(r2, z2) > 0.0 and sym < 1e-5, sym
+        res[semi] = (iters, relres, true_res, dev.kernel_counts()["mg_semi_levels"], dev.stats()["p_solver"])
+        dev.close()
+    it, rr, tr, levels, solver = res[1]
+    assert levels >= 3 and res[0][3] == 0 and solver == "mg-pcg", res
+    assert rr <= 1e-8 and tr <= 2e-8, res
+    assert it <= bound and it <= res[0][0], res
+
+
 def _krylov_case(mesh, bc, per_i, per_j, mode, tol=1e-8, options=None):
     from test_gpu_parity import _device_for
     ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
