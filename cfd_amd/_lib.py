@@ -142,6 +142,7 @@ SIGNATURES.update({
     "cfd_rccl_ranks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "cfd_comm_counts": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "cfd_comm_counts_by_phase": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
+    "cfd_extra_device_bytes": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "cfd_level_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cfd_level_smoother": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, C.POINTER(C.c_int)]),
 })

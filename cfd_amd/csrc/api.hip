@@ -148,6 +148,8 @@ static size_t workspace_bytes_impl(int ni, int nj, int nranks, int min_rows, siz
     size_t total = (size_t)N_FINE_PLANES * align256(lv[0].plane_elems() * sizeof(double));
     for (size_t l = 1; l < lv.size(); ++l) total += 6 * align256(lv[l].plane_elems() * sizeof(double));
     if (nranks > 1) total += 3 * align256(gs.plane_elems() * sizeof(double));
+    // single-precision copies of the face planes of every multigrid level (option mg_f32, on by default)
+    for (size_t l = 0; l < lv.size(); ++l) total += 2 * align256(lv[l].plane_elems() * sizeof(float));
     total += MISC_BYTES + bc_bytes + 4096;
     return total;
 }
@@ -291,6 +293,13 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
             L.s0 = (double *)cv.take(sb); L.s1 = (double *)cv.take(sb); L.s2 = (double *)cv.take(sb);
         }
     }
+    // single-precision face planes (build_pressure_hierarchy hands them out level by level)
+    {
+        size_t fb = 0;
+        for (size_t l = 0; l < lv.size(); ++l) fb += 2 * align256(lv[l].plane_elems() * sizeof(float));
+        c->f32_mem = (char *)cv.take(fb);
+        c->f32_mem_bytes = c->f32_mem ? fb : 0;
+    }
     c->partials = (double *)cv.take((size_t)8 * MAX_PARTIALS * sizeof(double));
     c->scal = (double *)cv.take(2048);
     c->bc_buf = (char *)cv.take(bc_bytes_for(ni, nj));
@@ -341,7 +350,6 @@ int cfd_destroy(cfd_ctx *ctx) {
     if (c->sst_mem) hipFree(c->sst_mem);
     if (c->line_mem) hipFree(c->line_mem);
     if (c->semi_mem) hipFree(c->semi_mem);
-    if (c->f32_mem) hipFree(c->f32_mem);
     if (c->wall_xy) hipFree(c->wall_xy);
     delete ctx;
     return CFD_OK;
@@ -382,6 +390,14 @@ int cfd_comm_counts(cfd_ctx *ctx, long long counts[3], int *native) {
     CTX(ctx);
     if (counts) { counts[0] = c->comm.n_halo; counts[1] = c->comm.n_reduce; counts[2] = c->comm.n_gather; }
     if (native) *native = c->comm.rccl != nullptr;
+    return CFD_OK;
+}
+
+int cfd_extra_device_bytes(cfd_ctx *ctx, size_t *bytes) {
+    CTX(ctx);
+    if (!bytes) { set_error("cfd_extra_device_bytes: null"); return CFD_E_ARG; }
+    const size_t pb = c->g.plane_elems() * sizeof(double);
+    *bytes = c->line_mem_bytes + c->semi_mem_bytes + (c->sst_mem ? 11 * pb : 0) + (size_t)c->n_wall * 2 * sizeof(double);
     return CFD_OK;
 }
 

@@ -386,9 +386,10 @@ struct Ctx {
     // (sst_mem, made by cfd_set_turbulence_model) so that k-omega and laminar runs do not pay for them
     int turb_model = 0;           // CFD_TURB_KOMEGA / CFD_TURB_SST
     char *sst_mem = nullptr;
-    char *line_mem = nullptr;      // Thomas factor planes of the line-smoothed multigrid levels (own allocation)
+    char *line_mem = nullptr;      // Thomas factor planes of the line-smoothed multigrid levels (own allocation, made when a
+                                   // hierarchy with such levels is built: stretched meshes only; cfd_extra_device_bytes)
     size_t line_mem_bytes = 0;
-    char *f32_mem = nullptr;       // single-precision face planes of the fused multigrid levels (own allocation)
+    char *f32_mem = nullptr;       // single-precision face planes of the fused multigrid levels (part of the workspace)
     size_t f32_mem_bytes = 0;
     int rr_byproduct = 1;          // (r, r) of the iteration before the expected last one from the next pre-smoother
     int mg_v32_emul = 0;           // measurement aid: the fused V-cycle kernels round what they store (x, coarse right-hand side, correction) to single precision

@@ -2756,13 +2756,8 @@ int build_pressure_hierarchy(Ctx *c) {
             want[l] = 1;
             need += 2 * ((c->levels[l].g.plane_elems() * sizeof(float) + 255) / 256 * 256);
         }
-        if (need > c->f32_mem_bytes) {
-            if (c->f32_mem) CFD_HIP(hipFree(c->f32_mem));
-            c->f32_mem = nullptr;
-            c->f32_mem_bytes = 0;
-            CFD_HIP(hipMalloc((void **)&c->f32_mem, need));
-            c->f32_mem_bytes = need;
-        }
+        // (carved from the context's workspace by cfd_create for every level, whether or not it ends up fused)
+        if (need > c->f32_mem_bytes) { set_error("internal: single-precision face planes exceed their share of the workspace"); return CFD_E_STATE; }
         size_t off = 0;
         for (int l = 0; l < nl; ++l) {
             if (!want[l]) continue;

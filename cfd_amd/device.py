@@ -55,6 +55,12 @@ class Device:
         check(self.lib.cfd_comm_counts(self._h, None, C.byref(native)))
         return bool(native.value)
 
+    def extra_device_bytes(self):
+        """Device bytes the context holds outside its workspace (SST planes, line-multigrid data of stretched meshes)."""
+        n = C.c_size_t(0)
+        check(self.lib.cfd_extra_device_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
     def rccl_ranks(self):
         """Ranks of the library's own RCCL communicator as RCCL reports them (0: none)."""
         n = C.c_int(0)

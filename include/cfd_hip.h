@@ -106,6 +106,13 @@ int cfd_version(void);
  * live in HBM.  workspace == NULL: the library hipMallocs cfd_workspace_bytes() itself;
  * otherwise the caller (e.g. a torch tensor) owns the memory, which lets the host
  * build zero-copy views for RCCL halo exchange.  device: HIP device ordinal.       */
+/* The workspace holds every plane a context needs on uniform and mildly stretched meshes, the single-precision face
+ * planes of the multigrid levels included.  Allocated by the library itself, outside the workspace, only when the
+ * case asks for them (cfd_extra_device_bytes reports the total): the Menter-SST planes (cfd_set_turbulence_model: 11
+ * planes), the wall-face list, and -- when the first pressure hierarchy of a STRETCHED mesh is built (coupling ratio
+ * above "mg_line_threshold") -- the line-multigrid data: semi-coarsened levels and their factors (about 13 planes'
+ * worth of bytes: 7.5 GB at 8192^2), or the block factors of the alternating line smoother (4 planes per level).
+ * A failed allocation is reported by the call that builds the hierarchy (CFD_E_HIP), not silently.                   */
 size_t cfd_workspace_bytes(int ni, int nj);
 int cfd_create(cfd_ctx **out, int ni, int nj, int device, void *workspace, size_t workspace_bytes);
 int cfd_destroy(cfd_ctx *ctx);
@@ -155,6 +162,8 @@ int cfd_comm_counts(cfd_ctx *ctx, long long counts[3], int *native);
 int cfd_comm_counts_by_phase(cfd_ctx *ctx, long long counts[27]);
 /* refresh the cut ghost rows of a field plane (after cfd_upload_field on every rank)            */
 int cfd_exchange_field(cfd_ctx *ctx, int field_id);
+/* device bytes this context currently holds outside its workspace (see cfd_workspace_bytes)       */
+int cfd_extra_device_bytes(cfd_ctx *ctx, size_t *bytes);
 /* number of multigrid levels and index of the first replicated one (0 on a single rank)         */
 int cfd_level_info(cfd_ctx *ctx, int *n_levels, int *first_replicated);
 /* multigrid level `level` of the built pressure hierarchy: its size, the largest strong / weak coupling ratio of
@@ -418,7 +427,9 @@ int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, doub
  * residual norms), "plane_swap" (1 / 0: Chebyshev results adopted by pointer exchange / copied), "xcd_map", "mg_gamma",
  * "mg_om0" .. "mg_om2" (smoother dampings), "mg_f32" (1 / 0: the multigrid levels of the pressure preconditioner carry
  * face coefficients rounded to single precision -- the Krylov operator stays double, the solution is unchanged),
- * "mg_v32_emul" (measurement aid), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
+ * "mg_semi" (1 / 0: stretched meshes are cycled by zebra whole-line relaxation along i with semi-coarsening along j /
+ * by the alternating block line smoother with full coarsening; one rank, frozen operator, lines of at most 8192 cells),
+ * "probe_capacity" (launches a probe run can time), "mg_v32_emul" (measurement aid), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
  * next pre-smoothing pass / by its own pass).  INTEGRATION.md section 4 has the table.  No counterpart in the reference.     */
 int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
 /* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels
