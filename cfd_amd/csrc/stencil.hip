@@ -865,8 +865,12 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
 // instead of 264.  Two halo lanes / rows per side (the gradient of p' needs one more than the fluxes).  The memory
 // ghosts of u, v, p are filled by k_flow_bc afterwards, as before.  u*, v* are read by neighbouring waves, so the
 // corrected u, v go to two other planes (the caller rebinds the plane pointers).
-// Conditions (launch_correct_flux checks them): one rank, no periodicity along j, every entry of the j-side tables
+// Conditions (launch_correct_flux checks them): no periodicity along j, every entry of the j-side tables
 // AFFINE / SYMMETRY (u, v) and AFFINE (p), the i-sides either periodic (with the p wrap) or like the j-sides.
+// j-slabs: a cut is to this kernel what a segment boundary is -- the wave corrects the neighbour's row beyond the cut
+// itself (row -1 / nj, bitwise what the neighbour computes: same expressions on the same operands) instead of
+// building a ghost row.  That takes p' two rows deep, u*, v*, u0, v0, p0, a_P (and k) one row deep and the metric
+// planes in the ghost rows (once per mesh: launch_correct_flux).
 // ----------------------------------------------------------------------------------
 constexpr int CFW = 60;
 struct CorrIn {
@@ -927,8 +931,9 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
         const bool ilo = iraw == 0, ihi = iraw == g.ni;
         const bool glo = !ci.per_i && iraw == -1, ghi = !ci.per_i && iraw == g.ni;      // ghost lanes of a non-periodic i-direction
         const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
+        const int rlo = g.cutlo ? -2 : -1, rhi = g.cuthi ? g.nj + 1 : g.nj;      // rows the planes hold
         auto fetchE = [&](int r, CorrE &R) {
-            const int rr = r < -1 ? -1 : (r > g.nj ? g.nj : r);
+            const int rr = r < rlo ? rlo : (r > rhi ? rhi : r);
             const size_t c = (size_t)(rr + NG) * P + colw;
             R.pc = ci.pc[(size_t)(rr + NG) * P + colp];
             R.wnj = m.wnj[c]; R.njx = m.njx[c]; R.njy = m.njy[c];
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             return KG ? (2.0 / 3.0) * ma.kgrad[(size_t)(rr + NG) * P + (size_t)((iraw < g.ni ? (iraw < -1 ? -1 : iraw) : g.ni) + CO)] : 0.0;
         };
         auto fetchL = [&](int r, CorrL &R) {
-            const int rr = r < -1 ? -1 : (r > g.nj ? g.nj : r);
+            const int rr = r < rlo ? rlo : (r > rhi ? rhi : r);
             const size_t c = (size_t)(rr + NG) * P + colw;
             R.us = ci.us[c]; R.vs = ci.vs[c]; R.u0 = ci.u0[c]; R.v0 = ci.v0[c]; R.p0 = ci.p0[c];
             R.ap = ci.ap[c]; R.vol = m.vol[c];
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
         double pcA;
         CorrE Eb, Ec, Ed;
         CorrL Lb, Lc;
-        auto correct_row = [&](int r, FluxRow &R) {       // r in [0, nj), in the form the flux stage reads
+        auto correct_row = [&](int r, FluxRow &R) {       // r in [0, nj) (-1 / nj beyond a cut), in the form the flux stage reads
             const double pcc = Eb.pc;
             const double pW = lane_left(pcc), pE = lane_right(pcc);
             // east face of the cell = west face of the right lane (lane ihi holds face ni, the east face of cell ni - 1)
@@ -987,15 +992,18 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             // ghost columns of a non-periodic i-direction from the neighbouring interior lane (k_flow_bc)
             const double uR = lane_right(un), vR = lane_right(vn), pR = lane_right(pn2);
             const double uL = lane_left(un), vL = lane_left(vn), pL = lane_left(pn2);
-            if (glo) bc_ghost(bc.side[CFD_SIDE_IMIN], r, uR, vR, pR, un, vn, pn2);
-            if (ghi) bc_ghost(bc.side[CFD_SIDE_IMAX], r, uL, vL, pL, un, vn, pn2);
+            // (rows beyond a cut have no table entry of this rank: their ghost columns are read by no cell that is stored)
+            const int tr = r < 0 ? 0 : (r >= g.nj ? g.nj - 1 : r);
+            if (glo) bc_ghost(bc.side[CFD_SIDE_IMIN], tr, uR, vR, pR, un, vn, pn2);
+            if (ghi) bc_ghost(bc.side[CFD_SIDE_IMAX], tr, uL, vL, pL, un, vn, pn2);
             R.u = un; R.v = vn; R.p = pn2; R.ap = rc ? Lb.ap : 1.0;
             R.wri = Lb.wri; R.nix = Lb.nix; R.niy = Lb.niy; R.si = Lb.si;
             R.wnj = Eb.wnj; R.njx = Eb.njx; R.njy = Eb.njy; R.sj = Lb.sj;
             R.vol = Lb.vol; R.k = Lb.k; R.lmin = Lb.lmin;
         };
-        // first interior row this segment needs corrected
-        const int r0 = j0 > 0 ? j0 - 1 : 0;
+        // first row this segment needs corrected
+        const bool below = j0 > 0 || g.cutlo;        // there is a row below the segment (another segment's or the neighbour slab's)
+        const int r0 = below ? j0 - 1 : 0;
         FluxRow cur{}, prv{};
         {
             CorrE A;
@@ -1009,7 +1017,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
         }
         int wrow = r0;                        // the row Eb / Lb hold
         bool have_cur = false;
-        if (j0 == 0) {
+        if (!below) {
             // the ghost row -1 stands in prv: the flux stage reads only its u, v, p (and k), from the corrected row 0
             correct_row(0, cur);
             prv = cur;
@@ -1019,8 +1027,8 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
         }
         double u2 = 0.0, v2 = 0.0, p2 = 0.0, k2 = 0.0;
         double fw_p = 0.0, fs_p = 0.0, lw_p = 0.0, ls_p = 0.0;
-        for (int j = j0 > 0 ? j0 - 1 : 0; j <= j1; ++j) {
-            if (j < g.nj) {
+        for (int j = r0; j <= j1; ++j) {
+            if (j < g.nj || g.cuthi) {
                 if (!have_cur) {
                     if (wrow != j) {          // window -> row j
                         pcA = Eb.pc; Eb = Ec; Ec = Ed; Lb = Lc;
@@ -1254,9 +1262,13 @@ static int finish_continuity(Ctx *c, int nb, double *out, bool with_dt = false) 
 
 // Host side of k_correct_flux: can this context take the fused pass, and the launch.
 bool correct_flux_ok(const Ctx *c) {
-    if (!c->fuse_correct || !c->march_flux || !c->rhs_lookahead || c->comm.nranks > 1 || c->g.cutlo || c->g.cuthi) return false;
+    if (!c->fuse_correct || !c->march_flux || !c->rhs_lookahead) return false;
     if (c->per_j || c->pp_per_j || c->g.ni < 8 || c->g.nj < 4) return false;
-    if (c->fbc_class[CFD_SIDE_JMIN] != 2 || c->fbc_class[CFD_SIDE_JMAX] != 2) return false;
+    // every rank of a slab run must decide alike (the pass has its own exchanges): fuse_correct_slab is set by
+    // cfd_set_flow_bc_tables' callers only through options, the side classes of the cut sides do not matter
+    if (c->comm.nranks > 1 && !c->fuse_correct_slab) return false;
+    if (!c->g.cutlo && c->fbc_class[CFD_SIDE_JMIN] != 2) return false;
+    if (!c->g.cuthi && c->fbc_class[CFD_SIDE_JMAX] != 2) return false;
     if (c->per_i) return c->fbc_class[CFD_SIDE_IMIN] == 1 && c->fbc_class[CFD_SIDE_IMAX] == 1 && c->wrap_p_i && c->pp_per_i;
     return c->fbc_class[CFD_SIDE_IMIN] == 2 && c->fbc_class[CFD_SIDE_IMAX] == 2 && !c->pp_per_i;
 }
@@ -1266,6 +1278,23 @@ bool correct_flux_ok(const Ctx *c) {
 // iteration, the continuity sum and (laminar runs) the next step's time-step minima in the partial sums.
 // The caller flips c->cur, fills the memory ghosts (k_flow_bc) and reads the sums (finish_correct_flux).
 int launch_correct_flux(Ctx *c, double dt, double ru, double rv, double rp, bool *dt_too_out, int *nb_out) {
+    if (c->comm.nranks > 1) {
+        const Geo &g = c->g;
+        if (!c->mesh_halo2) {
+            // once per mesh: the neighbour's metric rows beyond the cuts (face-j planes two rows deep: row nj + 1 holds the
+            // south face of the neighbour's second row)
+            const HaloSpec cellp[7] = {{&g, 1, c->m_vol}, {&g, 1, c->m_wri}, {&g, 1, c->m_nix}, {&g, 1, c->m_niy},
+                                       {&g, 1, c->m_si}, {&g, 1, c->m_lmin}, {&g, 2, c->m_sj}};
+            const HaloSpec facep[3] = {{&g, 2, c->m_wnj}, {&g, 2, c->m_njx}, {&g, 2, c->m_njy}};
+            CFD_TRY(halo_exchange_multi(c, 4, cellp));
+            CFD_TRY(halo_exchange_multi(c, 3, cellp + 4));
+            CFD_TRY(halo_exchange_multi(c, 3, facep));
+            c->mesh_halo2 = true;
+        }
+        // u*, v* (flow_bc after the predictor), u0, v0, p0 (flow_bc at the start of the iteration), a_P (do_predictor) and
+        // k (turbulence update) hold the neighbour's rows already
+        CFD_TRY(halo_exchange(c, g, 2, c->pcorr));
+    }
     FluxMarch fm = flux_march_geo(c->g);
     fm.nstrips = (c->g.ni + CFW - 1) / CFW;
     {

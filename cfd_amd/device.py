@@ -306,7 +306,7 @@ class Device:
                 "mom_solver": "chebyshev" if s.mom_solver == 1 else "bicgstab",
                 "k_solver": "chebyshev" if s.k_solver == 1 else "bicgstab",
                 "mom_relres": tuple(s.mom_relres), "p_relres": s.p_relres, "k_relres": tuple(s.k_relres),
-                "p_unconverged": s.p_unconverged}
+                "p_unconverged": s.p_unconverged, "transport_stalled": s.transport_stalled}
 
     def bulk_velocity(self, field_id=_lib.F_U):
         out = C.c_double()

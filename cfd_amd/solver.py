@@ -592,6 +592,11 @@ def run_case(config):
             warnings.warn(f"{stats['p_unconverged']} pressure solve(s) stopped at maxiter above solver.pressure.tol "
                           "(frozen operator: continued like the reference's cached-pyamg branch, solver.py:829-833)",
                           RuntimeWarning, stacklevel=2)
+        if stats["transport_stalled"]:
+            import warnings
+            warnings.warn(f"{stats['transport_stalled']} transport solve(s) were asked for a tolerance below 1e-12 and "
+                          "stalled between 1e-12 and 1e-10 after two restarts: accepted at the accuracy reached "
+                          "(include/cfd_hip.h: transport_stalled)", RuntimeWarning, stacklevel=2)
     finally:
         dev.close()
     return fields, step, time

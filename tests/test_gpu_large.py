@@ -457,6 +457,70 @@ def _wide_channel(turbulent):
     return cfg, mp, kind
 
 
+def _square_channel(turbulent):
+    return cases.channel_forced(n=256, steps=3, turbulent=turbulent, ratio_j=1.01)
+
+
+DEFAULT_PATH_CASES = {
+    # 17 strips of 60 columns: lockstep workgroups of 8 (wide_mask default), the fused closing pass, point-smoothed multigrid
+    "channel_1024x64": (lambda: _wide_channel(False), {"mg_line": 0}),
+    "channel_komega_1024x64": (lambda: _wide_channel(True), {"mg_line": 0}),
+    # wall-graded (dy max / min = 12.6): every tuning at its default, the pressure solve through the line-smoothed multigrid
+    "channel_256x256": (lambda: _square_channel(False), {}),
+    "channel_komega_256x256": (lambda: _square_channel(True), {}),
+}
+# p of the 256^2 k-omega run: the pressure correction turns an error du of the predictor into a_P h du, and with
+# nu_t up to 3.5e3 on cells of 8.5e-4 (a_P h ~ nu_t / dy <= 4e6, |u| / |p| = 280 in rms) even du = eps |u| may show up
+# as 2e-7 |p|: 1e-10 is not attainable for this field on this case by any solver that is not bitwise the reference's.
+# Measured: 5.2e-10 with the transport solves at 1e-15 (2.4e-8 at 1e-13).  Asserted: 2e-9; every other field 1e-10.
+P_BAR = {"channel_komega_256x256": 2.0e-9}
+
+
+@pytest.mark.parametrize("name", list(DEFAULT_PATH_CASES))
+def test_default_kernel_forms_against_oracle(name, tmp_path):
+    """The kernel forms the 8192^2 run takes by default (lockstep workgroups, correction fused into the closing flux
+    pass, single-precision multigrid storage) against the pinned CPU oracle with direct solves: three outer steps,
+    every solved field to 1e-10 -- the lockstep and fused forms are otherwise only compared with other GPU forms."""
+    builder, tuning = DEFAULT_PATH_CASES[name]
+    cfg, mp, kind = builder()
+    mesh = orc.rect_mesh(**mp)
+    cases.perturbed_parabola(cfg, mesh)
+    ref, rstep, rtime, hist = orc.run_case(cfg, mesh, solver_mode="direct", freeze_pressure=True)
+
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    cfg2, mp2, _ = builder()
+    cfg2["mesh"] = {"generator": hip_mesh.generate_rect_mesh, "params": mp2, "path": tmp_path / "mesh" / "mesh.npz"}
+    cfg2["paths"] = {"case_dir": tmp_path, "mesh_dir": tmp_path / "mesh", "states_dir": tmp_path / "states",
+                     "post_dir": tmp_path / "postproc"}
+    mesh2 = hip_mesh.make_mesh(cfg2["mesh"])
+    cases.perturbed_parabola(cfg2, mesh2)
+    cfg2["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
+    cfg2["solver"]["momentum"]["tol"] = TRANSPORT_TOL
+    if tuning:
+        cfg2["solver"]["tuning"] = dict(tuning)
+    fields, step, time = hip_solver.run_case(cfg2)
+    last = dict(hip_solver.LAST_RUN)
+    assert step == rstep == 3 and abs(time - rtime) <= 1e-11 * rtime
+    unorm = np.linalg.norm(ref["u"].ravel())
+    for key in ("u", "v", "p", "k", "omega", "nu_t"):
+        if key not in ref:
+            continue
+        err = np.linalg.norm((mask_corners(fields[key]) - mask_corners(ref[key])).ravel())
+        den = np.linalg.norm(mask_corners(ref[key]).ravel())
+        bar = P_BAR.get(name, FIELD_TOL) if key == "p" else FIELD_TOL
+        assert err <= bar * den + 1e-12 * unorm, (key, err, den)
+    log = np.loadtxt(tmp_path / "postproc" / f"{cfg2['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
+    conts = np.array([r["cont"] for r in hist])
+    assert np.all(np.abs(log[:, 3] - conts) <= 2e-6 * conts + 1e-12)
+    kc = last["kernel_counts"]
+    assert kc["correct_flux"] > 0 and kc["cheb4_2rhs"] > 0 and last["stats"]["p_unconverged"] == 0, (kc, last["stats"])
+    if "1024x64" in name:
+        assert kc["flux_march_multistrip"] > 0 and kc["mg_fused_levels_max"] >= 2, kc
+    else:
+        assert kc["mg_semi_levels"] >= 2 or kc["mg_line_levels_max"] >= 2, kc
+
+
 FUSED_CORRECTION_CASES = {
     "channel_forced_160x96": cases.LARGE_END_TO_END["channel_forced_160x96"],                  # periodic i, walls, three strips
     "channel_forced_komega_160x96": cases.LARGE_END_TO_END["channel_forced_komega_160x96"],    # + grad(2/3 k)
@@ -475,11 +539,16 @@ def test_correction_fused_into_the_closing_flux_pass(name, tmp_path):
     the same bits in every field; the continuity sum is taken over other strip widths (rounding)."""
     builder, fixup = FUSED_CORRECTION_CASES[name]
     # The turbulent half cylinder blows up in its first step, in the reference as here (nu_t ~ 1e9, dt ~ 1e-15, continuity
-    # ~ 1e6): whether the k solve of that state reaches the rounding level within its iteration budget hangs on the last
-    # bits of p, and with the single-precision multigrid faces (same solution to the tolerance, other last bits) it does not.
-    # The case is here for the symmetry rows and the curvilinear metrics of the fused kernel, so it keeps the double faces.
-    extra = {"mg_f32": 0} if name == "half_cylinder_komega_132x24" else None
-    (f1, log1, last1), (f0, log0, last0) = _run_pair(builder, fixup, tmp_path, extra)
+    # ~ 1e6): its k solve, asked for 1e-15, stalls at 7e-12 after 10000 Jacobi-BiCGStab iterations with the default
+    # single-precision multigrid faces (at 1e-13 with double faces: other last bits of p).  Such a stall below the rounding
+    # level is accepted and counted (transport_stalled), so the default options run this case too.
+    if name == "half_cylinder_komega_132x24":
+        with pytest.warns(RuntimeWarning, match="stalled"):
+            (f1, log1, last1), (f0, log0, last0) = _run_pair(builder, fixup, tmp_path, None)
+        assert last1["stats"]["transport_stalled"] > 0 and last0["stats"]["transport_stalled"] == last1["stats"]["transport_stalled"]
+    else:
+        (f1, log1, last1), (f0, log0, last0) = _run_pair(builder, fixup, tmp_path, None)
+        assert last1["stats"]["transport_stalled"] == 0
     assert last1["kernel_counts"]["correct_flux"] > 0 and last0["kernel_counts"]["correct_flux"] == 0
     for key in f0:
         assert np.array_equal(mask_corners(f1[key]), mask_corners(f0[key])), key

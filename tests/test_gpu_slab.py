@@ -76,6 +76,11 @@ def test_slab_run_matches_single_rank(case, world, min_rows, tmp_path):
     assert la.shape == lb.shape
     assert np.array_equal(la[:, 0], lb[:, 0]) and np.array_equal(la[:, 2], lb[:, 2])     # steps, inner iterations
     assert np.all(np.abs(la[:, 3] - lb[:, 3]) <= 1e-6 * np.abs(la[:, 3]) + 1e-13)        # continuity history
+    # the slabs close their iterations with the same fused correction / flux pass as the single rank (a cut is a segment
+    # boundary to that kernel); the half cylinder's j-sides are periodic / not local, so it keeps the separate kernels
+    assert (int(many["correct_flux"]) > 0) == (int(one["correct_flux"]) > 0), (int(one["correct_flux"]), int(many["correct_flux"]))
+    if "channel" in case or "couette" in case or "inlet" in case:
+        assert int(many["correct_flux"]) > 0
 
 
 @pytest.mark.parametrize("mode", ["rccl", "nccl-torch"])
