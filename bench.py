@@ -624,7 +624,8 @@ def main():
                                              ", halo rows + all-reduce + coarse-level all-gather "
                                              + ("enqueued by the library over RCCL" if dev.transport == "rccl" else
                                                 f"through torch.distributed ({args.backend}) callbacks")
-                                             + ", coarse multigrid levels replicated"
+                                             + ", multigrid levels %s slab-distributed, coarser ones replicated" % (
+                                                 "0..%d" % (dev.level_info()[1] - 1))
                                              + (f" [{dev.transport_note}]" if getattr(dev, "transport_note", None) else "")),
                        "collectives_per_step": None if dev.comm is None else dict(zip(
                            ("halo_exchanges", "all_reduces", "all_gathers"),

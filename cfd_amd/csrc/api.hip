@@ -1338,7 +1338,7 @@ int cfd_momentum_rhs_from(cfd_ctx *ctx, double dt, const double *adv_u, const do
 
 int cfd_wall_friction(cfd_ctx *ctx, int side, int lo, int hi, const double *t_hat, const double *dn, const double *seg_len,
                       double nu, double rho, int use_nu_t, double *tau, double out[2]) {
-    CTX_MUT(ctx);
+    CTX(ctx);          // reads u, v, nu_t and writes the staging plane only: the look-ahead of the step stays valid
     NEED_MESH();
     const int n = hi - lo + 1;
     const int limit = (side == CFD_SIDE_IMIN || side == CFD_SIDE_IMAX)
@@ -1359,6 +1359,9 @@ int cfd_wall_friction(cfd_ctx *ctx, int side, int lo, int hi, const double *t_ha
     CFD_HIP(hipStreamSynchronize(c->stream));
     CFD_TRY(launch_wall_friction(c, side, lo, n, tab, nu, rho, use_nu_t, tab + (size_t)4 * n, out));
     if (tau) {
+        // slabs: a rank fills the faces it owns and zeros elsewhere, the sum over the ranks is the reference's array
+        // (collective: every rank passes tau or none does)
+        CFD_TRY(all_reduce(c, tab + (size_t)4 * n, n, 0));
         CFD_HIP(hipMemcpyAsync(tau, tab + (size_t)4 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         CFD_HIP(hipStreamSynchronize(c->stream));
     }

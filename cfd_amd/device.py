@@ -441,6 +441,13 @@ class Device:
         check(self.lib.cfd_probe_read_id(self._h, int(kernel), C.byref(n), C.byref(us), C.byref(bpc)))
         return (n.value, us.value, bpc.value) if with_bytes else (n.value, us.value)
 
+    def level_info(self):
+        """(multigrid levels of the built pressure hierarchy, index of the first level that is replicated on every rank
+        of a slab run -- levels below it are slab-distributed; 0 levels before the first pressure solve)."""
+        n, first = C.c_int(), C.c_int()
+        check(self.lib.cfd_level_info(self._h, C.byref(n), C.byref(first)))
+        return n.value, first.value
+
     def level_smoothers(self):
         """[(ni, nj, strong / weak coupling ratio, line-smoothed?)] per multigrid level of the built pressure hierarchy."""
         n, first = C.c_int(), C.c_int()

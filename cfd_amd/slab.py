@@ -194,7 +194,21 @@ class SlabComm:
         check(lib.cfd_set_comm(handle, self._halo_c, self._reduce_c, self._gather_c, None))
 
 
-DEFAULT_MIN_SLAB_ROWS = 512
+# A multigrid level is replicated on every rank (operator gathered once, right-hand side gathered once per V-cycle, no
+# further messages) once the GLOBAL level has this few cells: such a level and everything below it is launch-latency
+# work on one GPU (<= 2 MiB gathered), while keeping it distributed costs two exchanges per V-cycle.  Above it a level
+# stays distributed: replicating a level of millions of cells would make every rank do the whole level's work.
+REPLICATE_BELOW_CELLS = 1 << 18
+DEFAULT_MIN_SLAB_ROWS = 512      # 8192^2 on two ranks under the rule above; kept as the fall-back of callers without a mesh size
+
+
+def default_min_slab_rows(ni, nj_global, world):
+    """Rows per slab of the coarsest level that stays slab-distributed under REPLICATE_BELOW_CELLS (>= 16, the library's
+    floor; slab levels halve the rows while they stay even): 512 for 8192^2 on 2 ranks, 256 on 4, 128 on 8."""
+    rows, ci, cj = int(nj_global) // int(world), int(ni), int(nj_global)
+    while rows % 2 == 0 and rows // 2 >= 16 and ((ci + 1) // 2) * (cj // 2) > REPLICATE_BELOW_CELLS:
+        rows, ci, cj = rows // 2, (ci + 1) // 2, cj // 2
+    return max(16, rows)
 
 
 def rehearsal_env(rank):
@@ -221,11 +235,17 @@ def attach_rccl(dev, group=None):
     import torch.distributed as dist
     ident = [None]
     if dev.rank == 0:
-        buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
-        check(dev.lib.cfd_rccl_unique_id(buf, _lib.RCCL_ID_BYTES))
-        ident[0] = buf.raw
+        # a failure here is broadcast like the id would be: no rank is left waiting in the collective below
+        try:
+            buf = C.create_string_buffer(_lib.RCCL_ID_BYTES)
+            check(dev.lib.cfd_rccl_unique_id(buf, _lib.RCCL_ID_BYTES))
+            ident[0] = buf.raw
+        except Exception as e:      # noqa: BLE001
+            ident[0] = ("failed", str(e))
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast_object_list(ident, src=src, group=group)
+    if isinstance(ident[0], tuple):
+        raise _lib.HipError("rank 0 could not create the RCCL id: " + ident[0][1])
     buf = C.create_string_buffer(ident[0], _lib.RCCL_ID_BYTES)
     check(dev.lib.cfd_set_comm_rccl(dev._h, buf, _lib.RCCL_ID_BYTES))
 
@@ -236,11 +256,13 @@ def slab_device(ni, nj_global, device=0, group=None, min_slab_rows=None, transpo
     (3 halo exchanges per level and V-cycle); coarser levels are replicated on every rank.
     transport: "rccl" (library-native RCCL), "torch" (torch.distributed callbacks); default: environment
     variable CFD_SLAB_TRANSPORT, else "rccl" under an nccl process group and "torch" otherwise."""
-    min_slab_rows = max(16, int(DEFAULT_MIN_SLAB_ROWS if min_slab_rows is None else min_slab_rows))
     import torch
     import torch.distributed as dist
     from .device import Device
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if min_slab_rows is None:
+        min_slab_rows = default_min_slab_rows(ni, nj_global, world)
+    min_slab_rows = max(16, int(min_slab_rows))
     rank = dist.get_rank(group) if world > 1 else 0
     j_off, nj_local = partition(nj_global, world, rank)
     if world == 1:

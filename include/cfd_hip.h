@@ -371,7 +371,8 @@ int cfd_momentum_rhs_from(cfd_ctx *ctx, double dt, const double *adv_u, const do
  * lo..hi (inclusive) of one side, from the u, v (and nu_t when use_nu_t) planes in HBM: nothing but O(hi - lo)
  * numbers crosses PCIe.  t_hat (n, 2), dn (n: |(fc - cc) . n_hat| floored at 1e-12), seg_len (n) are the host's
  * geometry of those faces (post_processing.py:103-170, 646, 654-655).  tau: optional host array of n shear stresses
- * (a j-slab rank fills its own faces, zero elsewhere); out = {sum tau * seg_len, sum seg_len} over all ranks.    */
+ * (j-slabs: summed over the ranks, every rank gets the whole array -- collective, so either every rank passes tau
+ * or none does); out = {sum tau * seg_len, sum seg_len} over all ranks.  Leaves the step's look-ahead state alone. */
 int cfd_wall_friction(cfd_ctx *ctx, int side, int lo, int hi, const double *t_hat, const double *dn, const double *seg_len,
                       double nu, double rho, int use_nu_t, double *tau, double out[2]);
 /* solve the two momentum systems for the stored RHS planes (solver.py:785-818, 885-894)     */

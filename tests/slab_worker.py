@@ -135,6 +135,46 @@ def kernel_check(name, out_dir, rank, world):
         dist.destroy_process_group()
 
 
+def friction_check(name, out_dir, rank, world):
+    """The in-loop friction diagnostic (cfd_wall_friction) on slabs: an i-side segment is split over the ranks, a j-side
+    segment belongs to the first / last rank; sums and the per-face shear stresses must be those of the single rank."""
+    import torch.distributed as dist
+    from cfd_amd import solver as S
+    from cfd_amd.bc import BoundaryGeometry
+    from cfd_amd.post_processing import WallFriction, friction_coefficient_device
+    from cfd_amd.slab import slab_device
+    work = out_dir / f"rank{rank}"
+    cfg = build_case(name, work)
+    mesh = S.load_mesh(cfg["mesh"])
+    ctl = S.StepControl(cfg)
+    fields = S.initialize_fields(mesh, cfg["initial"])
+    ni, nj = int(mesh["count_i"]), int(mesh["count_j"])
+    fields.setdefault("nu_t", np.zeros((ni + 2, nj + 2)))
+    dev = slab_device(ni, nj, 0, min_slab_rows=int(os.environ.get("SLAB_MIN_ROWS", "16")))
+    dev.upload_mesh(mesh)
+    S.configure_device(dev, cfg, BoundaryGeometry.from_nodes(mesh["node"]), cfg["physics"]["nu"], ctl.turb_on)
+    dev.upload_fields(fields)
+    dev.apply_flow_bc()
+    dt = dev.compute_dt(0.5, 0.5, 0.0, 1.0e-3)[0]
+    res = [dev.simple_iter(dt, 0.7, 0.7, 0.3) for _ in range(2)]
+    out = {}
+    for side, rng in (("i_min", None), ("i_max", (5, nj - 4)), ("j_min", None), ("j_max", (3, ni - 2))):
+        wall = WallFriction(mesh, side, rng)
+        got = friction_coefficient_device(dev, wall, nu=cfg["physics"]["nu"], want_tau=True)
+        out[f"{side}_cf"], out[f"{side}_tau"], out[f"{side}_tau_avg"] = got["cf"], got["tau"], got["tau_avg"]
+        # the scalars alone (no tau array: no extra collective)
+        again = friction_coefficient_device(dev, wall, nu=cfg["physics"]["nu"])
+        assert again["cf"] == got["cf"]
+    # the diagnostic leaves the step's look-ahead alone: the next iteration is the one a run without it takes
+    res.append(dev.simple_iter(dt, 0.7, 0.7, 0.3))
+    dev.close()
+    if rank == 0:
+        np.savez(out_dir / "result.npz", res=np.array(res), **out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     name, out_dir, mode = sys.argv[1], Path(sys.argv[2]), sys.argv[3]
     backend, transport = {"gloo": ("gloo", "torch"), "rccl": ("gloo", "rccl"), "nccl": ("nccl", None),
@@ -161,6 +201,8 @@ def main():
             cfd_amd.slab._rccl_probe = lambda dev: "simulated: RCCL not loadable"
     if name == "mesh_from_rect":
         return mesh_from_rect_check(out_dir, rank, world)
+    if name.startswith("friction:"):
+        return friction_check(name.split(":", 1)[1], out_dir, rank, world)
     if name.startswith("kernels:"):
         return kernel_check(name.split(":", 1)[1], out_dir, rank, world)
     from cfd_amd import solver as hip_solver

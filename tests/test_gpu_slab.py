@@ -173,3 +173,19 @@ def test_fused_kernels_across_cuts(case, world, tmp_path):
     assert int(one["mom_iters"]) == int(many["mom_iters"]) and int(one["p_iters"]) == int(many["p_iters"])
     assert int(one["cheb"]) == int(many["cheb"]) == 1
     assert np.allclose(one["res"], many["res"], rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("case,world", [("inlet_outlet_40x32", 2), ("channel_komega_48x64", 4)])
+def test_wall_friction_on_slabs(case, world, tmp_path):
+    """cfd_wall_friction on slabs (the friction log of run_case on every rank): i-side segments cross the cuts, j-side
+    segments sit on one rank; sub-ranges start and end inside a slab.  Sums to rounding (other order), the per-face
+    shear stresses exactly (each face is computed by one rank, the others add zeros)."""
+    one = _run("friction:" + case, 1, tmp_path / "w1")
+    many = _run("friction:" + case, world, tmp_path / f"w{world}")
+    for side in ("i_min", "i_max", "j_min", "j_max"):
+        a, b = one[f"{side}_tau"], many[f"{side}_tau"]
+        assert a.shape == b.shape and a.size > 0
+        assert np.abs(a - b).max() <= 1e-9 * max(np.abs(a).max(), 1e-300), side      # fields equal to the solver tolerance
+        # (the mean over an inlet plane cancels to rounding: measured against the largest face value)
+        assert abs(float(one[f"{side}_tau_avg"]) - float(many[f"{side}_tau_avg"])) <= 1e-9 * np.abs(a).max() + 1e-300, side
+    assert np.allclose(one["res"], many["res"], rtol=1e-6, atol=1e-14)

@@ -26,6 +26,18 @@ def test_partition():
         partition(64, 4, 4)
 
 
+def test_default_replication_threshold_follows_the_global_level_size():
+    """A multigrid level is replicated once the global level has <= 2^18 cells: 8192^2 keeps 4 slab-distributed levels
+    whatever the rank count (the round-2 constant 512 replicated a 4096 x 2048 level on every one of 8 ranks)."""
+    from cfd_amd.slab import default_min_slab_rows
+    assert default_min_slab_rows(8192, 8192, 2) == 512
+    assert default_min_slab_rows(8192, 8192, 4) == 256
+    assert default_min_slab_rows(8192, 8192, 8) == 128
+    assert default_min_slab_rows(64, 256, 8) == 32            # small mesh: never distributed below the finest level
+    assert default_min_slab_rows(2048, 2048, 2) == 512
+    assert default_min_slab_rows(8192, 8192 * 8, 8) == 256     # weak-scaling channel 8192 x 65536: 6 distributed levels
+
+
 def test_boundary_tables_slab():
     """Slab tables = the global tables restricted to the slab rows; k/omega ops re-based."""
     from cfd_amd import _lib as L
