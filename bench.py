@@ -41,15 +41,16 @@ sys.path.insert(0, str(REPO))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
 # 8192^2 (tools/pmc_summary.py: FETCH_SIZE x 2 + WRITE_SIZE, fabric side, Infinity-Cache hits included)
-PMC_TRAFFIC_BYTES_PER_CELL_8192 = {}       # filled from profiles/r2*_pmc8192_bytes_per_cell.csv when present
+PMC_TRAFFIC_BYTES_PER_CELL_8192 = {}       # filled from the newest profiles/r*_pmc8192_bytes_per_cell.csv of the uniform laminar run
 PMC_KERNEL_OF_PROBE = {0: "k_cg_pq", 8: "k_chebk<2,4", 9: "k_chebk<1,4", 7: "k_mg_up_k<true", 1: "k_mg_down_k<true,3,false",
                        10: "k_mg_down_k<true,3,true", 2: "k_correct_flux<"}
 
 
 def load_pmc_traffic():
     """bytes per cell and launch of the probed kernels from the newest committed PMC summary (tools/pmc_summary.py)."""
-    # laminar passes only: the k-omega passes are named r2?_komega_pmc8192_* (tools/profile_komega.sh)
-    files = sorted(f for f in (REPO / "profiles").glob("r2*_pmc8192_bytes_per_cell.csv") if "komega" not in f.name)
+    # the uniform laminar passes only: k-omega / graded / annulus passes carry their workload in the file name
+    files = sorted(f for f in (REPO / "profiles").glob("r[0-9]*_pmc8192_bytes_per_cell.csv")
+                   if not any(w in f.name for w in ("komega", "graded", "annulus")))
     if not files:
         return None, {}
     out = {}
@@ -267,6 +268,47 @@ def second_leg(args, n, world, local, barrier, torch, dist, strong):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
+def variant_legs(args, local, budget_s, steps=3, warmup=2):
+    """Outside the timed region, single GPU: ms per outer step of the OTHER workloads of the same size -- the wall-graded
+    channel and the half annulus (stretched meshes: the reference's own cases are all wall-graded; pressure solve through
+    the semi-coarsened line multigrid) and the k-omega channel -- so that the driver's line carries them.  Bounded: a
+    variant is skipped once the budget is spent."""
+    from cfd_amd.solver import advance_one_step
+    n = args.size
+    todo = (("graded", f"{n}x{n} periodic channel, wall-graded mesh (max / min dy = 20), laminar",
+             lambda: setup_device(n, False, args.max_iter, args.tol, local, graded=True)),
+            ("annulus", f"{n}x{n // 2} half annulus around a cylinder (r 0.5 .. 20), laminar",
+             lambda: setup_annulus(n, n // 2, args.max_iter, args.tol, local)),
+            ("komega", f"{n}x{n} periodic channel, uniform mesh, k-omega",
+             lambda: setup_device(n, True, args.max_iter, args.tol, local)))
+    out, t_start = [], time.perf_counter()
+    for name, text, make in todo:
+        if time.perf_counter() - t_start > budget_s:
+            out.append({"variant": name, "workload": text, "skipped": "time budget of the variants leg spent"})
+            continue
+        dev, ctl, _ = make()
+        try:
+            step, its = 0, []
+            for _ in range(warmup):
+                advance_one_step(dev, ctl, step)
+                step += 1
+            dev.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                advance_one_step(dev, ctl, step)
+                its.append(dev.stats()["p_iters"])
+                step += 1
+            dev.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            cells = n * (n // 2) if name == "annulus" else n * n
+            out.append({"variant": name, "workload": text, "ms_per_step": 1e3 * dt, "cell_updates_per_s": cells / dt, "steps": steps,
+                        "warmup": warmup, "mean_pressure_iters": float(np.mean(its)),
+                        "mg_semi_levels": dev.kernel_counts()["mg_semi_levels"]})
+        finally:
+            dev.close()
+    return out
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -391,6 +433,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="(default for N > 1; kept for older command lines)")
     ap.add_argument("--no-second-leg", action="store_true",
                     help="N > 1: skip the leg in the other scaling mode that follows the timed region")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the untimed leg that reports ms per step of the graded / annulus / k-omega workloads (N = 1)")
+    ap.add_argument("--variants-budget", type=float, default=100.0, help="seconds the variants leg may take")
     ap.add_argument("--shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use GPU 0 (with --backend gloo), numbers are not a measurement")
     ap.add_argument("--rehearse-launch", action="store_true",
@@ -478,11 +523,15 @@ def main():
     # device time is the `roofline` kernel and the others are reported beside it, all from the timed steps themselves
     shares = {}
     probe_id = args.probe
-    for _ in range(args.warmup):
+    # the event pool exists and the stream has seen its first timed event records before the timed region starts (the first
+    # record on a stream costs milliseconds once): the probe is switched on for the last warm-up step and reset after it
+    dev.set_option("probe_capacity", min(16384, 160 * (args.steps + 1) * max(1, args.max_iter) // 2 + 64))
+    for w in range(args.warmup):
+        if w == args.warmup - 1:
+            dev.probe(L.PROBE_ALL if probe_id < 0 else probe_id)
         info = advance_one_step(dev, ctl, step)
         step += 1
     dev.synchronize()
-    dev.set_option("probe_capacity", min(16384, 160 * (args.steps + 1) * max(1, args.max_iter) // 2 + 64))
     dev.probe(L.PROBE_ALL if probe_id < 0 else probe_id)
     comm0 = dev.comm_counts()
     phase0 = dev.comm_counts_by_phase()
@@ -670,6 +719,20 @@ def main():
                    "coarse_level_bytes_per_cell_per_vcycle": coarse_bytes_per_vcycle}
             note = ("algorithmic bytes from the launch mix of the timed steps (per solve); time = device time of the pressure "
                     "phase (right-hand side kernel, solve, host residual checks) over the two steps that follow the timed region")
+        elif kcounts.get("mg_semi_levels", 0) > 0:
+            # semi-coarsened line multigrid (stretched meshes): per cell of a level and V-cycle the four zebra half
+            # sweeps read b (4 x 8 B / 2), the other colour's x (3 x 8 / 2), the coarse correction (8 / 2), c_j in
+            # single precision (3 x 8 / 2), the line factors (4 x F / 2: l, 1 / p, and z on periodic lines, 4 B each) and
+            # write x (3 x 8 / 2) and the coarse right-hand side (8 / 2): 60 + 2 F; the levels halve, so x 2 per fine
+            # cell.  Krylov side per iteration: direction step 64 B (z in double here), residual update 24 B.
+            fac = 12.0 if args.mesh == "graded" else 8.0
+            per_it = 64.0 + 24.0 + 2.0 * (60.0 + 2.0 * fac)
+            bytes_per_solve = per_it * mean_p_it + 112.0
+            mix = {"semi_coarsened_levels": kcounts["mg_semi_levels"], "vcycle_bytes_per_fine_cell": 2.0 * (60.0 + 2.0 * fac),
+                   "krylov_bytes_per_iteration": 88.0, "rhs_pass": 112.0}
+            note = ("semi-coarsened line multigrid: algorithmic bytes of a zebra line V(1,1) cycle over all levels + direction step "
+                    "+ residual update, x iterations + right-hand side; time = device time of the pressure phase over the two steps "
+                    "that follow the timed region")
         else:
             # line-smoothed / curvilinear workloads and forced single-kernel probes: nominal V(3,3)-PCG bytes per iteration
             f8 = 8.0 if f32 else 0.0
@@ -704,6 +767,8 @@ def main():
         else:
             out["cpu_baseline"] = None
     dev.close()
+    if world == 1 and not args.no_variants and args.mesh == "uniform" and not args.turbulent and n >= 64:
+        out["variants"] = variant_legs(args, local, args.variants_budget)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

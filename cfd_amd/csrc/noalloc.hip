@@ -10,6 +10,7 @@
 // Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two host threads) race
 // on the partial sums.  Nothing has to start at zero: a call overwrites exactly the partials that its second kernel
 // reads (blocks 0 .. nb-1 of both rows), so the contents a previous, larger call left behind are never looked at.
+#include <atomic>
 #include <mutex>
 
 #include "internal.h"
@@ -23,22 +24,27 @@ constexpr int NA_MAX_DEVICES = 64;
 
 static __device__ __align__(256) double scratch[NA_SCRATCH_DOUBLES];      // 64 KiB per GPU, held until the process ends
 
-static double *g_scratch[NA_MAX_DEVICES] = {};
+static std::atomic<double *> g_scratch[NA_MAX_DEVICES] = {};
 static std::mutex g_scratch_mutex;
 
-// device address of this GPU's copy of `scratch` (looked up on the first call on that GPU, with it current)
+// device address of this GPU's copy of `scratch`: looked up once per GPU, with it current (cfd_create does it, else the
+// first call of the entry point on that GPU: that one call may load the code object and takes a mutex; every later
+// call is one atomic load)
 static int scratch_ptr(double **out) {
     int dev = -1;
     CFD_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= NA_MAX_DEVICES) { set_error("cfd_bulk_velocity_noalloc: device ordinal %d out of range", dev); return CFD_E_ARG; }
-    std::lock_guard<std::mutex> lock(g_scratch_mutex);
-    if (!g_scratch[dev]) {
-        double *ptr = nullptr;
-        CFD_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
-        if (!ptr) { set_error("cfd_bulk_velocity_noalloc: hipGetSymbolAddress returned a null pointer"); return CFD_E_HIP; }
-        g_scratch[dev] = ptr;
+    double *ptr = g_scratch[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        ptr = g_scratch[dev].load(std::memory_order_relaxed);
+        if (!ptr) {
+            CFD_HIP(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+            if (!ptr) { set_error("cfd_bulk_velocity_noalloc: hipGetSymbolAddress returned a null pointer"); return CFD_E_HIP; }
+            g_scratch[dev].store(ptr, std::memory_order_release);
+        }
     }
-    *out = g_scratch[dev];
+    *out = ptr;
     return CFD_OK;
 }
 

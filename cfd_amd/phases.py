@@ -21,6 +21,7 @@ from .device import Device
 _WALLS = {side: {"type": "wall"} for side in ("i_min", "i_max", "j_min", "j_max")}
 _MAX_ENGINES = 2
 _engines = {}           # id(mesh["cell_volume"]) -> Engine, most recently used last
+_turb_state = {"model": "k_omega"}      # the closure the last initialize() call validated (turbulence.py:10-13, 257)
 
 
 def _turbulence_on(cfg):
@@ -354,6 +355,7 @@ def initialize(fields, mesh, cfg, bc_cfg=None):
         raise ValueError("Initial omega is missing; set it in initial scalars.")
     if "nu_t" not in fields:
         fields["nu_t"] = np.zeros((int(mesh["count_i"]) + 2, int(mesh["count_j"]) + 2), dtype=float)
+    _turb_state["model"] = cfg.get("model")          # what sources() / effective_diffusivity() go by (turbulence.py:257)
     return fields
 
 
@@ -403,13 +405,64 @@ def eddy_viscosity(fields, cfg):
 
 
 # ---------------------------------------------------------------- helpers
+class _PlanesOnly:
+    """GPU context of a field SHAPE, without a mesh: what the pointwise closures (eddy_viscosity, sources,
+    effective_diffusivity -- none of them has a mesh argument in the reference) need."""
+
+    def __init__(self, ni, nj):
+        self.ni, self.nj = int(ni), int(nj)
+        self.dev = Device(self.ni, self.nj)
+        self.model = None
+        self.nut_zero = False
+
+    def close(self):
+        self.dev.close()
+
+
 def _engine_for_shape(shape):
-    """The cached engine whose ghosted field shape matches (eddy_viscosity has no mesh argument)."""
+    """The cached engine whose ghosted field shape matches, else a mesh-less context of that shape."""
     for eng in reversed(list(_engines.values())):
         if (eng.ni + 2, eng.nj + 2) == tuple(shape):
             return eng
-    raise RuntimeError("eddy_viscosity: no GPU context for this field shape yet; call a function that takes the mesh "
-                       "first (turbulence.apply_bcs does)")
+    if len(shape) != 2 or min(shape) < 3:
+        raise ValueError(f"ghosted (Ni+2, Nj+2) field expected, got shape {tuple(shape)}")
+    while len(_engines) >= _MAX_ENGINES:
+        _engines.pop(next(iter(_engines))).close()
+    eng = _PlanesOnly(shape[0] - 2, shape[1] - 2)
+    _engines[("planes", eng.ni, eng.nj)] = eng
+    return eng
+
+
+def sources(fields, grad_u, grad_v, mesh=None):
+    """turbulence.sources (turbulence.py:401-444): (source_k, source_omega) on the interior cells from k, omega, nu_t
+    and the caller's velocity gradients -- the Wilcox closure, one pointwise kernel (cfd_komega_sources).  The model
+    is the one the last initialize() call saw, as in the reference (_turb_state).  The SST sources need the wall
+    distance, the blending caches and the cell-centre differences of a transport step and exist only inside
+    update_turbulence here (cfd_turbulence_step): asking for them stand-alone is an error, not a silent k-omega answer."""
+    if _turb_state.get("model", "k_omega") == "sst":
+        raise NotImplementedError("SST sources are evaluated inside update_turbulence (cfd_turbulence_step) only")
+    eng = _engine_for_shape(np.shape(fields["k"]))
+    dev = eng.dev
+    for name in ("k", "omega", "nu_t"):
+        dev.upload(_lib.FIELD_IDS[name], fields[name])
+    eng.nut_zero = False
+    return dev.komega_sources(grad_u, grad_v)
+
+
+def effective_diffusivity(nu, nu_t, field="k", fields=None):
+    """turbulence.effective_diffusivity (turbulence.py:541-577): nu + sigma nu_t (sigma_k = sigma_omega = 0.5) on the
+    ghosted shape of nu_t; under SST the blended planes _D_k / _D_omega a transport step left in `fields`."""
+    if fields is not None and _turb_state.get("model") == "sst":
+        key = "_D_k" if field == "k" else "_D_omega"
+        if key in fields:
+            return fields[key]
+    if field not in ("k", "omega"):
+        raise ValueError(f"Unsupported field '{field}' for effective_diffusivity.")
+    arr = np.asarray(nu_t, dtype=float)
+    eng = _engine_for_shape(arr.shape)
+    eng.dev.upload(_lib.F_NUT, arr)
+    eng.nut_zero = False
+    return eng.dev.effective_diffusivity(float(nu), 0.5)
 
 
 def _set_tolerances(eng, mom=None, p=None, turb=None, freeze=False):

@@ -334,7 +334,11 @@ int cfd_bulk_velocity(cfd_ctx *ctx, int field_id, double *out);
  * partial sums live in a fixed 64 KiB device array of the library (one copy per GPU, held until the process ends):
  * at most 32768 x 32768 cells, larger sizes are rejected (CFD_E_ARG); calls that overlap on one GPU race on that
  * array, calls that follow each other (any sizes) do not.  Same kernels, tiles and summation order as
- * cfd_bulk_velocity: the mean has the same bits.                                                              */
+ * cfd_bulk_velocity: the mean has the same bits (pitch may exceed the library's own, any stream of the device).
+ * FIRST USE ON A DEVICE: the address of that device's copy of the array is looked up once (hipGetSymbolAddress
+ * under a mutex, which may load the code object) -- by cfd_create on that device, else by the first call of this
+ * entry point there.  A caller that is under HIP graph capture, or must not block, makes one plain call (or a
+ * cfd_create) on the device beforehand; every later call allocates nothing, locks nothing and looks nothing up.  */
 int cfd_bulk_velocity_noalloc(const double *field_dev, const double *volume_dev, int ni, int nj, int pitch,
                               void *hip_stream, double *out_dev);
 

@@ -86,6 +86,42 @@ def test_turbulence_apply_bcs_and_eddy_viscosity(tag):
 
 
 @pytest.mark.parametrize("tag", TAGS)
+def test_turbulence_pointwise_closures_without_a_mesh(tag):
+    """turbulence.sources / effective_diffusivity / eddy_viscosity have no mesh argument (turbulence.py:362, 401, 541):
+    they run on a GPU context of the field shape, created on first use -- no earlier call that saw the mesh is
+    needed.  Sources bit-exact against the reference's vectors (src_k, src_omega of gen_golden.function_vectors)."""
+    from cfd_amd import phases, turbulence
+    g, ph, mesh, bc_cfg, nu, _ = _load(tag)
+    phases.release()                                            # no context of any mesh is alive
+    cfg = {"enabled": True, "model": "k_omega"}
+    s = _state(g)
+    turbulence.initialize(s, mesh, cfg)                         # host bookkeeping only: records the closure
+    sk, sw = turbulence.sources(s, g["grad_u"], g["grad_v"])
+    assert sk.shape == sw.shape == g["src_k"].shape
+    assert np.array_equal(sk, g["src_k"]) and np.array_equal(sw, g["src_omega"])
+    for field in ("k", "omega"):
+        d = turbulence.effective_diffusivity(nu, s["nu_t"], field)
+        assert d.shape == s["nu_t"].shape and np.array_equal(d, nu + 0.5 * s["nu_t"])
+    with pytest.raises(ValueError, match="Unsupported field"):
+        turbulence.effective_diffusivity(nu, s["nu_t"], "epsilon")
+    phases.release()
+    fresh = {k: s[k].copy() for k in ("k", "omega")}
+    fresh["nu_t"] = np.zeros_like(s["k"])
+    nut = turbulence.eddy_viscosity(fresh, cfg)                 # first GPU call of this shape
+    assert nut is fresh["nu_t"] and np.array_equal(nut, g["nu_t"])
+    # SST: the blended planes a transport step cached in `fields` are handed back; the stand-alone sources are refused
+    sst = {"enabled": True, "model": "sst"}
+    turbulence.initialize(s, mesh, sst)
+    cached = dict(s, _D_k=np.full_like(s["k"], 2.0), _D_omega=np.full_like(s["k"], 3.0))
+    assert turbulence.effective_diffusivity(nu, s["nu_t"], "k", cached) is cached["_D_k"]
+    assert turbulence.effective_diffusivity(nu, s["nu_t"], "omega", cached) is cached["_D_omega"]
+    assert np.array_equal(turbulence.effective_diffusivity(nu, s["nu_t"], "omega", s), nu + 0.5 * s["nu_t"])
+    with pytest.raises(NotImplementedError):
+        turbulence.sources(s, g["grad_u"], g["grad_v"], mesh)
+    turbulence.initialize(s, mesh, cfg)                         # back to k-omega for the tests that follow
+
+
+@pytest.mark.parametrize("tag", TAGS)
 def test_compute_adaptive_dt(tag):
     from cfd_amd import solver
     g, ph, mesh, _, nu, _ = _load(tag)

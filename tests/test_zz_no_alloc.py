@@ -1,6 +1,7 @@
 """cfd_bulk_velocity_noalloc (the entry point that allocates nothing, include/cfd_hip.h) against cfd_bulk_velocity:
 same bits, on two calls in a row of which the second has the smaller input (the static scratch array keeps the first
-call's partial sums)."""
+call's partial sums).  The second call also runs on a stream of the caller's and on planes with a pitch larger than
+the library's own (a caller's allocation): neither changes tiles or summation order."""
 import ctypes as C
 
 import numpy as np
@@ -31,7 +32,8 @@ def test_no_alloc_entry_point_matches_bulk_velocity():
     ng = lib.cfd_ghost_rows()
     rng = np.random.default_rng(3)
     keep = []
-    for ni, nj in ((700, 520), (96, 40)):       # second call: fewer workgroups than the first left partial sums for
+    # second call: fewer workgroups than the first left partial sums for; user stream; padded pitch
+    for ni, nj, own_stream, pad in ((700, 520, False, 0), (96, 40, True, 64)):
         mesh = orc.rect_mesh(2.0, 1.0, ni, nj, 1.01, 1.03)
         u = np.zeros((ni + 2, nj + 2))
         u[1:-1, 1:-1] = rng.standard_normal((ni, nj)) + 0.3
@@ -39,12 +41,14 @@ def test_no_alloc_entry_point_matches_bulk_velocity():
         dev.upload_mesh(mesh)
         dev.upload(L.F_U, u)
         want = dev.bulk_velocity(L.F_U)
-        pitch = dev.pitch
+        pitch = dev.pitch + pad
         dev.close()
         f_pl, w_pl = _planes(torch, ni, nj, pitch, ng, mesh["cell_volume"], u[1:-1, 1:-1], lib.cfd_col_offset())
         out = torch.full((3,), float("nan"), dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        stream = torch.cuda.current_stream().cuda_stream
+        user = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+        stream = user.cuda_stream
+        assert not own_stream or stream != torch.cuda.current_stream().cuda_stream
         L.check(lib.cfd_bulk_velocity_noalloc(C.c_void_p(f_pl.data_ptr()), C.c_void_p(w_pl.data_ptr()), ni, nj, pitch,
                                               C.c_void_p(stream), C.c_void_p(out.data_ptr())))
         torch.cuda.synchronize()
@@ -53,7 +57,7 @@ def test_no_alloc_entry_point_matches_bulk_velocity():
         ref = float((u[1:-1, 1:-1] * mesh["cell_volume"]).sum() / mesh["cell_volume"].sum())
         assert abs(got[0] - ref) <= 1e-13 * abs(ref)
         assert abs(got[2] - mesh["cell_volume"].sum()) <= 1e-13 * got[2]
-        keep.append((f_pl, w_pl, out))
+        keep.append((f_pl, w_pl, out, user))
     # sizes beyond the stated maximum are rejected with a clear error, nothing is launched
     rc = lib.cfd_bulk_velocity_noalloc(C.c_void_p(keep[0][0].data_ptr()), C.c_void_p(keep[0][1].data_ptr()), 40000, 8, 40032,
                                        None, C.c_void_p(keep[0][2].data_ptr()))

@@ -3,7 +3,10 @@
 kernel and HBM bytes per cell and launch.  FETCH_SIZE counts one unit per 2 KiB (MI355X_MICROARCH.md, HBM; confirmed on this
 code's access patterns by tools/stream_probe2.hip under --pmc, profiles/r2_fetch_size_calibration.txt); WRITE_SIZE is exact.
 
-    python tools/pmc_summary.py r1g [cells]
+    python tools/pmc_summary.py r1g [cells] [line-factor bytes: 12 periodic lines, 8 otherwise]
+
+Stretched meshes (semi-coarsened line multigrid): the k_semi_* instantiations serve several levels each, so they are
+summed per V-cycle instead of listed per launch (appended to the bytes-per-cell file).
 """
 import csv
 import glob
@@ -78,11 +81,12 @@ def per_kernel(pattern, counter):
     return tot, cnt
 
 
-stats = {}
+stats, calls = {}, {}
 spath = glob.glob(f"gpurun_out/{tag}_stats/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(spath, f"profiles/{tag}_bench8192_kernel_stats.csv")
 for r in csv.DictReader(open(spath)):
     stats[short(r["Name"])] = (float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
+    calls[short(r["Name"])] = int(r["Calls"])
 shutil.copy(f"gpurun_out/{tag}_bench.json", f"profiles/{tag}_bench8192.json")
 
 ft, fc = per_kernel(f"gpurun_out/{tag}_fetch/**/*counter_collection.csv", "FETCH_SIZE")
@@ -116,4 +120,19 @@ with open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv", "w") as f:
         us, share = stats[k]
         f.write(";".join([k, f"{fr + wr:.2f}", f"{fr:.2f}", f"{wr:.2f}", f"{a}", f"{(fr + wr) / a:.3f}", f"{us:.1f}", f"{share:.2f}",
                           str(fc[k]), f"{a * cells / us / 1e6:.2f}"]) + "\n")
+semi = [k for k in ft if k.startswith("k_semi_") and not k.startswith(("k_semi_factor", "k_semi_to_f32"))]
+if semi:
+    fac = float(sys.argv[3]) if len(sys.argv) > 3 else 12.0
+    coarsest = [k for k in semi if k.startswith("k_semi_coarsest")]
+    vc_pmc = sum(fc[k] for k in coarsest)                  # V-cycles seen by the counter pass
+    vc_stats = sum(calls.get(k, 0) for k in coarsest)      # ... by the kernel-trace pass
+    fetch = sum(ft[k] for k in semi) * 1024.0 * FACTOR / vc_pmc / cells
+    write = sum(wt.get(k, 0.0) for k in semi) * 1024.0 / max(1, sum(wc.get(k, 0) for k in coarsest)) / cells
+    us = sum(stats[k][0] * calls[k] for k in semi if k in stats) / max(1, vc_stats)
+    algo = 2.0 * (60.0 + 2.0 * fac)
+    with open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv", "a") as f:
+        f.write("# semi-coarsened line multigrid, all k_semi_* launches of one V-cycle (every level), per FINE cell:\n")
+        f.write("semi_vcycle;total_B_per_cell;fetch_B_per_cell;write_B_per_cell;algorithmic_B_per_cell;ratio;us_per_vcycle;vcycles_timed;algorithmic_TBps\n")
+        f.write(";".join(["k_semi_*", f"{fetch + write:.2f}", f"{fetch:.2f}", f"{write:.2f}", f"{algo:.1f}", f"{(fetch + write) / algo:.3f}",
+                          f"{us:.1f}", str(vc_stats), f"{algo * cells / us / 1e6:.2f}"]) + "\n")
 print(open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv").read())
