@@ -10,17 +10,19 @@ resident in HBM before the timed region.  metric = cell-updates/s = Ni*Nj*n_gpus
     torchrun ... bench.py --gpus N ...                        (ranks from the launcher's environment)
 
 The JSON line also carries
-  roofline     : the probed hot kernel with the largest share of device time (found live: one untimed step per
-                 candidate before the warm-up), timed with HIP-event pairs around EVERY launch inside the timed steps;
+  roofline     : the probed hot kernel (instantiations of one kernel grouped) with the largest share of device time,
+                 found live from HIP-event pairs around EVERY launch of every candidate inside the timed steps;
                  achieved = sum of the algorithmic bytes of those launches / sum of their durations (the bytes differ
                  per launch for some kernels: the first two PCG direction steps of a solve skip planes, the first
                  Chebyshev launch has no x_{k-1}; the library reports them with the times), peak 8.0 TB/s.  --probe N
-                 forces a kernel.  All candidates are reported in roofline_other_kernels (one extra step each).
+                 forces a kernel.  All candidates are reported in roofline_other_kernels (same timed steps).
                  traffic = HBM bytes per launch from the committed PMC passes of this command, quoted only for the
                  single-GPU default size they were measured on.
   N > 1        : the headline is BASELINE.json's configuration, the --size x --size channel split into N j-slabs
                  ("scaling": "strong"); the weak-scaling variant (one --size x --size slab per GPU of a channel N
                  times as high) is timed afterwards and reported as weak_scaling_leg (--weak makes it the headline).
+  variants     : N = 1, after the timed region: ms per step of the wall-graded channel, the half annulus and the k-omega
+                 channel at the same size (three steps each, --variants-budget seconds; --no-variants skips them).
   cpu_baseline : the CPU oracle with the reference's solver mix (ILU-BiCGStab momentum, factor-once LU pressure)
                  timed on this host at 256^2, 512^2 and 1024^2 (--cpu-size), bounded by --cpu-budget seconds.
 """

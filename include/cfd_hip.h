@@ -225,12 +225,11 @@ int cfd_set_solver(cfd_ctx *ctx, double mom_tol, int mom_maxiter, double p_tol, 
  * the temporally blocked marching kernels (all sweeps of a pass in one kernel) when
  * nu_pre = nu_post = 2 or 3                                                                 */
 int cfd_set_multigrid(cfd_ctx *ctx, int nu_pre, int nu_post, double omega, int coarse_sweeps, int fused);
-/* Damping of the odd smoothing sweeps (the even ones use `omega` of cfd_set_multigrid); the sweeps of one
- * pass commute, so the preconditioner stays symmetric.  Defaults omega = 1.0, omega2 = 0.6: the smoothing
- * factor of plain 0.8 / 0.8 on [0.5, 2] of the Jacobi-scaled spectrum (0.35) with a root at 1;
- * omega = 0.5617, omega2 = 1.3895 would be the degree-2 Chebyshev smoother on that interval; omega2 <= 0:
- * `omega` on every sweep.  The single-block coarsest solve uses the mean of the two.  (Replaces pyamg's
- * smoother choice, solver.py:821-833.)                                                                  */
+/* Two-factor form of cfd_set_smoother_omegas (kept for callers of round 1): damping of the odd smoothing sweeps, the
+ * even ones use `omega` of cfd_set_multigrid; the sweeps of one pass commute, so the preconditioner stays symmetric.
+ * omega2 <= 0: `omega` on every sweep.  The single-block coarsest solve uses the mean of the factors.  The DEFAULT
+ * dampings are the three of cfd_set_smoother_omegas below, not a pair.  (Replaces pyamg's smoother choice,
+ * solver.py:821-833.)                                                                                   */
 int cfd_set_smoother_omega2(cfd_ctx *ctx, double omega2);
 /* General form: n = 1..4 damping factors in (0, 2), mean <= 1, used cyclically by the sweeps of a pass.
  * Default: V(3,3) with (1.25, 0.5, 1.0) (three sweeps fused per pass: 5 MG-PCG iterations per solve at
