@@ -1,5 +1,6 @@
 // C ABI of libcfd_hip.so (see include/cfd_hip.h): context, host<->device layout
 // conversion, and the sequencing of one SIMPLE iteration / PISO step / k-omega step.
+#include <functional>
 #include <algorithm>
 #include <cstdarg>
 #include <cstring>
@@ -309,6 +310,8 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
     c->ws_used = cv.used;
     e = hipHostMalloc((void **)&c->h_scal, 256 * sizeof(double));
     if (e != hipSuccess) { c->h_scal = nullptr; set_error("hipHostMalloc failed"); return fail(CFD_E_HIP); }
+    e = hipHostMalloc((void **)&c->h_spec, 256 * sizeof(double));
+    if (e != hipSuccess) { c->h_spec = nullptr; set_error("hipHostMalloc failed"); return fail(CFD_E_HIP); }
     // carve the BC buffer
     {
         const size_t n = (size_t)(ni > nj ? ni : nj);
@@ -348,6 +351,7 @@ int cfd_destroy(cfd_ctx *ctx) {
     if (c->ev_read) hipEventDestroy(c->ev_read);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->h_scal) hipHostFree(c->h_scal);
+    if (c->h_spec) hipHostFree(c->h_spec);
     if (c->own_ws && c->ws) hipFree(c->ws);
     if (c->sst_mem) hipFree(c->sst_mem);
     if (c->line_mem) hipFree(c->line_mem);
@@ -657,6 +661,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "fuse_correct") c->fuse_correct = iv ? 1 : 0;
     else if (n == "fuse_correct_slab") c->fuse_correct_slab = iv ? 1 : 0;
     else if (n == "skip_fresh_bc") c->skip_fresh_bc = iv ? 1 : 0;
+    else if (n == "speculate") c->speculate = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "wide_mask") { if (iv < 0 || iv > 1023) { set_error("wide_mask: 0 .. 1023"); return CFD_E_ARG; } c->wide_mask = iv; }
@@ -1005,10 +1010,53 @@ int cfd_compute_dt(cfd_ctx *ctx, int use_cfl, double cfl, int use_cfl_diff, doub
     return CFD_OK;
 }
 
+// One inner iteration, speculative where the context allows it (internal.h: Ctx::speculate): `body` runs with the solves
+// replaying their previous schedules and a single host read at its end; if a stopping test then turns out not to hold
+// (or the replay itself gave up), the iteration is undone -- c->cur back: u, v, p of the start are untouched in their
+// half of the ping-pong planes, everything else an iteration writes is recomputed -- and repeated host-checked.
+static int run_iteration(Ctx *c, double *res, const std::function<int()> &body) {
+    // auto (-1): where a host read costs a noticeable share of the step.  On a large slab the reads are < 1 % of the step
+    // while one repeated iteration costs half a step, so the host-checked path stays the default there.
+    const bool want = c->speculate > 0 || (c->speculate < 0 && (long)c->g.ni * c->g.nj <= Ctx::SPEC_AUTO_CELLS);
+    const bool spec = want && c->host_lag && c->march_flux && c->freeze_pressure && c->p_built && c->spec_age < Ctx::SPEC_RENEW;
+    const int cur0 = c->cur;
+    c->spec_cheb = Ctx::SpecCheb{};
+    c->spec_pcg = Ctx::SpecPcg{};
+    c->spec_on = spec;
+    int rc = body();
+    c->spec_on = false;
+    if (!spec) {
+        c->spec_age = 0;
+        return rc;
+    }
+    bool ok = rc == CFD_OK;
+    const bool any = c->spec_cheb.used || c->spec_pcg.n > 0;
+    if (ok) CFD_TRY(spec_verify(c, res, &ok));
+    if (ok) {
+        if (any) { ++c->spec_age; c->kc[KC_SPEC_ITERS] += 1; }
+        else c->spec_age = 0;                  // nothing was replayed: this was a host-checked iteration
+        return CFD_OK;
+    }
+    c->kc[KC_SPEC_REDONE] += 1;
+    c->cur = cur0;
+    c->rhs_ahead = false; c->dt_ahead = false; c->dt_host_valid = false; c->bc_fresh = false;
+    c->spec_cheb = Ctx::SpecCheb{};
+    c->spec_pcg = Ctx::SpecPcg{};
+    c->spec_age = 0;
+    return body();
+}
+
+static int simple_iter_body(Ctx *c, double dt, double relax_u, double relax_v, double relax_p, double res[3]);
+static int piso_step_body(Ctx *c, double dt, int n_correctors, double relax_u, double relax_v, double relax_p, double res[3]);
+
 int cfd_simple_iter(cfd_ctx *ctx, double dt, double relax_u, double relax_v, double relax_p, double res[3]) {
     CTX(ctx);
     CFD_TRY(ready(c));
     if (!(dt > 0.0)) { set_error("dt must be positive"); return CFD_E_ARG; }
+    return run_iteration(c, res, [&]() { return simple_iter_body(c, dt, relax_u, relax_v, relax_p, res); });
+}
+
+static int simple_iter_body(Ctx *c, double dt, double relax_u, double relax_v, double relax_p, double res[3]) {
     c->dt_ahead = false;
     bool fused = false;
     CFD_TRY(use_correct_flux(c, &fused));
@@ -1058,6 +1106,10 @@ int cfd_piso_step(cfd_ctx *ctx, double dt, int n_correctors, double relax_u, dou
     CTX(ctx);
     CFD_TRY(ready(c));
     if (!(dt > 0.0) || n_correctors < 1) { set_error("cfd_piso_step: bad arguments"); return CFD_E_ARG; }
+    return run_iteration(c, res, [&]() { return piso_step_body(c, dt, n_correctors, relax_u, relax_v, relax_p, res); });
+}
+
+static int piso_step_body(Ctx *c, double dt, int n_correctors, double relax_u, double relax_v, double relax_p, double res[3]) {
     c->dt_ahead = false;
     bool fused = false;
     CFD_TRY(use_correct_flux(c, &fused));

@@ -196,7 +196,7 @@ __device__ __forceinline__ void store_stream_f32(float *p, float v, int nt) {
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
-    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_COUNT = 16
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_SPEC_ITERS, KC_SPEC_REDONE, KC_COUNT = 18
 };
 
 // ------------------------------------------------------------------ multigrid level
@@ -326,6 +326,41 @@ struct Ctx {
     double p_sym_tol = 1.0e-5;         // relative seam asymmetry of the frozen pressure operator up to which it is solved by PCG
     double p_seam_asym = 0.0;          // the measured one (diagnostic)
     int fuse_correct_slab = 1;         // ... also on j-slab contexts (every rank must hold the same value)
+    // Speculative inner iteration (option "speculate"; needs host_lag and the marching flux kernels): the
+    // Chebyshev momentum solve and the MG-PCG pressure solve replay the schedule of the previous iteration (which
+    // right-hand side leaves after which iteration; how many PCG iterations) WITHOUT host reads, leaving the residual
+    // sums their stopping tests would have looked at in device slots; the one read that ends the iteration (continuity
+    // sum, time-step minima) brings those slots along and the stopping tests are evaluated then.  A test that fails
+    // means a solve needed more iterations than last time: the iteration is undone (its inputs are still in the other
+    // half of the ping-pong planes) and repeated on the host-checked path, which also renews the schedule.  Every
+    // SPEC_RENEW-th iteration runs host-checked anyway so that the schedule can shrink.
+    int speculate = -1;                // -1: on for contexts of <= SPEC_AUTO_CELLS cells, 0 / 1: off / on
+    static constexpr long SPEC_AUTO_CELLS = 1L << 22;
+    bool spec_on = false;              // inside a speculative iteration
+    int spec_age = 0;                  // speculative iterations since the last host-checked one
+    static constexpr int SPEC_RENEW = 48;
+    double *h_spec = nullptr;          // pinned host copy of Ctx::scal (256 doubles), filled by the closing read
+    struct ChebPlan {
+        bool valid = false;
+        const double *D = nullptr;     // the operator the schedule belongs to
+        int nb = 0, K = 0;
+        double tol = 0.0;
+        int retire_k[2] = {0, 0};      // iterate each right-hand side was taken from
+    } cheb_plan;
+    static constexpr int SPEC_MAX_LAUNCHES = 12;
+    struct SpecCheb {
+        bool used = false;
+        int nb = 0, K = 0, launches = 0;
+        double tol = 0.0;
+        int na[SPEC_MAX_LAUNCHES] = {};            // right-hand sides in launch m (0-based)
+        int t[SPEC_MAX_LAUNCHES][2] = {};          // position of right-hand side q among them, -1: not in the launch
+        int k[2] = {0, 0};                         // iterate each right-hand side was taken from
+    } spec_cheb;
+    struct SpecPcg {
+        int n = 0;
+        int hint[4] = {0, 0, 0, 0};
+        double tol[4] = {0, 0, 0, 0};
+    } spec_pcg;
     int cf_agreed = -1;                // slab ranks' common answer to correct_flux_ok (-1: not asked yet)
     bool bc_fresh = false;             // the ghosts of u, v, p [bc_cur] are those of k_flow_bc + exchange on the current values
     int bc_cur = -1, skip_fresh_bc = 1;
@@ -550,6 +585,8 @@ int read_scalars(Ctx *c, int off, int n, double *host);
 int read_scalars_begin(Ctx *c, int off, int n);             // enqueue the copy into h_scal[off ..) and record ev_read
 int read_scalars_end(Ctx *c, int off, int n, double *host); // wait for ev_read only
 int read_scalars2(Ctx *c, int off1, int n1, double *host1, int off2, int n2, double *host2);   // two ranges, one synchronisation
+int read_scalars_all(Ctx *c);                           // the whole of Ctx::scal into Ctx::h_spec, one synchronisation
+int spec_verify(Ctx *c, double *res, bool *ok);         // stopping tests of a speculative iteration on that copy
 int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2], int nb,
                         double tol, int maxiter, int *iters, double relres[2], double rms[2]);
 int build_pressure_hierarchy(Ctx *c);

@@ -92,6 +92,11 @@ int read_scalars_end(Ctx *c, int off, int n, double *host) {
     for (int q = 0; q < n; ++q) host[q] = c->h_scal[off + q];
     return CFD_OK;
 }
+int read_scalars_all(Ctx *c) {
+    CFD_HIP(hipMemcpyAsync(c->h_spec, c->scal, 256 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CFD_HIP(hipStreamSynchronize(c->stream));
+    return CFD_OK;
+}
 int read_scalars2(Ctx *c, int off1, int n1, double *host1, int off2, int n2, double *host2) {
     CFD_HIP(hipMemcpyAsync(c->h_scal + off1, c->scal + off1, n1 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (n2 > 0) CFD_HIP(hipMemcpyAsync(c->h_scal + off2, c->scal + off2, n2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -221,6 +226,12 @@ struct BiScal {
 constexpr int BI_OFF = 16;   // offset of BiScal inside Ctx::scal (in doubles)
 constexpr int RR_HIST_OFF = 112;     // Ctx::scal slots: |r|^2 of the last PCG iterations (index it & 7)
 constexpr int CHEB_SAVE_OFF = 104;   // Ctx::scal slots: the sums of the first Chebyshev launch of a solve (read one launch later)
+// Ctx::scal slots of a speculative iteration (internal.h: Ctx::speculate): Chebyshev [0, 6) sums of the first launch
+// (|r_0|^2, |r_{K-1}|^2, |b|^2 per right-hand side), then four slots per later launch (|r_k0|^2, |r_{k0+K-1}|^2 of the
+// right-hand sides still in it); MG-PCG: per solve of the iteration 8 history slots of |r|^2 and |b|^2
+constexpr int SPEC_CHEB_OFF = 128, SPEC_CHEB_SLOTS = 8 + 4 * (Ctx::SPEC_MAX_LAUNCHES - 1);      // 128 .. 179
+constexpr int SPEC_PCG_OFF = 192, SPEC_PCG_STRIDE = 10;                                        // 192 .. 231
+constexpr double SPEC_MARGIN = 0.5;      // a schedule moves to an earlier iterate only if that one met the test with this factor to spare
 
 __device__ __forceinline__ double safe_div(double a, double b) { return b != 0.0 ? a / b : 0.0; }
 
@@ -2164,6 +2175,18 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
     };
     const bool lag = c->host_lag && c->cheb_lag_ok;
     bool first_pending = false;
+    // speculative replay (internal.h: Ctx::speculate): this solve takes each right-hand side from the iterate the previous
+    // solve with this operator took it from; the sums its stopping test needs stay on the device until the iteration ends
+    const Ctx::ChebPlan plan = c->cheb_plan;
+    const int spec_kmax = std::min(maxiter, K * Ctx::SPEC_MAX_LAUNCHES);
+    const bool spec = c->spec_on && !c->spec_cheb.used && plan.valid && plan.D == op.D && plan.nb == NB && plan.K == K &&
+                      plan.tol == tol && plan.retire_k[0] < spec_kmax && plan.retire_k[NB - 1] < spec_kmax;
+    if (!spec && op.D == c->ap) c->cheb_plan.valid = false;      // renewed below if this solve ends inside the Chebyshev iteration
+    if (spec) {
+        Ctx::SpecCheb &sc = c->spec_cheb;
+        sc = Ctx::SpecCheb{};
+        sc.used = true; sc.nb = NB; sc.K = K; sc.tol = tol;
+    }
     for (int m = 1;; ++m) {
         int qs[2], na = 0;
         for (int q = 0; q < NB; ++q)
@@ -2234,6 +2257,39 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         c->kc[K == 4 ? (na == 2 ? KC_CHEB4_2RHS : KC_CHEB4_1RHS) : KC_CHEB2] += 1;
         CFD_HIP(hipGetLastError());
         int k0 = K * (m - 1);                      // this launch measured |r_k0| and |r_{k0+K-1}|
+        if (spec) {
+            // the sums of every launch go to slots of their own (this rank's part; one all-reduce over all of them when the
+            // solve ends): the closing read sees the whole residual history and can move the schedule either way
+            Ctx::SpecCheb &sc = c->spec_cheb;
+            const int off = m == 1 ? SPEC_CHEB_OFF : SPEC_CHEB_OFF + 8 + 4 * (m - 2);
+            // m = 1: [t] |r_0|^2, [na + t] |r_{K-1}|^2, [2 na + t] |b|^2 (na = NB); later: [t] |r_k0|^2, [na + t] |r_{k0+K-1}|^2
+            hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, st, c->partials, (int)grid.x, m == 1 ? 3 * na : 2 * na, c->scal + off);
+            CFD_HIP(hipGetLastError());
+            sc.launches = m;
+            sc.na[m - 1] = na;
+            sc.t[m - 1][0] = sc.t[m - 1][1] = -1;
+            for (int t = 0; t < na; ++t) sc.t[m - 1][qs[t]] = t;
+            for (int t = 0; t < na; ++t) {
+                const int q = qs[t], kr = plan.retire_k[q];
+                if (kr != k0 && kr != k0 + K - 1) continue;
+                sc.k[q] = kr;
+                final_where[q] = kr == k0 ? cur_k[q] : set[m & 1][0][q];
+                act[q] = false;
+                kdone[q] = kr;
+                relres[q] = 0.0;                   // filled in when the iteration's closing read has arrived (spec_verify)
+                if (rms) rms[q] = 0.0;
+            }
+            if (!act[0] && !act[NB - 1]) {
+                *iters = std::max(kdone[0], kdone[NB - 1]);
+                *used = 1;
+                CFD_TRY(all_reduce(c, c->scal + SPEC_CHEB_OFF, 8 + 4 * (m - 1), 0));
+                return deliver(true);
+            }
+            bool overdue = false;                  // (a schedule whose points this launch sequence never visits: not replayable)
+            for (int q = 0; q < NB; ++q) overdue = overdue || (act[q] && plan.retire_k[q] < k0 + K);
+            if (overdue) { set_error("Chebyshev replay: schedule point missed"); return CFD_E_STATE; }
+            continue;
+        }
         // The sums of the first launch (|r_0|, |b|: how many iterations to expect) are looked at one launch later
         // when the previous solve needed a second launch too: the copy is enqueued behind launch 1, the host waits
         // for it only after launch 2 is in the queue, so the GPU does not idle while the host decides.
@@ -2297,6 +2353,11 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                 *iters = std::max(kdone[0], kdone[NB - 1]);
                 *used = 1;
                 c->cheb_lag_ok = m >= 2 && !late_first;
+                if (op.D == c->ap) {               // the momentum solve's schedule, which a speculative iteration replays
+                    c->cheb_plan.valid = true;
+                    c->cheb_plan.D = op.D; c->cheb_plan.nb = NB; c->cheb_plan.K = K; c->cheb_plan.tol = tol;
+                    c->cheb_plan.retire_k[0] = kdone[0]; c->cheb_plan.retire_k[1] = kdone[NB - 1];
+                }
                 return deliver(true);
             }
             if (late_first) continue;                // now the sums of launch 2 itself, if it is time for them
@@ -2457,7 +2518,7 @@ static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double 
 // Relative residuals below this are the rounding level of the fp64 recurrences: a solve that stagnates there
 // although a tighter tolerance was asked for (the 1e-13 of the parity runs) counts as converged.
 constexpr double ROUNDING_LEVEL_RELRES = 1.0e-12;
-constexpr double STALL_ACCEPT_RELRES = 1.0e-10;
+constexpr double STALL_ACCEPT_RELRES = 1.0e-6;      // (the reference ends in a direct solve there, whatever its accuracy: solver.py:809-818)
 
 int momentum_like_solve(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
                         int nb, double tol, int maxiter, int *iters, double relres[2], double rms[2]) {
@@ -3381,6 +3442,10 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     int it = 0;
     const int hint0 = c->p_iters_hint;
     int converged_at = -1;
+    // speculative iteration (internal.h: Ctx::speculate): as many iterations as the previous solve needed, |r|^2 of the last
+    // two and |b|^2 kept in device slots for the iteration's closing read instead of being read here
+    const bool spec = c->spec_on && lazy_bb && fused && hint0 >= 1 && hint0 < maxiter && c->spec_pcg.n < 4;
+    bool spec_pending = false;
     // Iterations whose |r| the host does not look at leave r = r - alpha q to the pre-smoother of the next V-cycle
     // (k_mg_down_k<true, 3, true>): r ping-pongs between the right-hand side plane and kry[1].  Needs the three-sweep
     // marching kernels on the finest level; on j-slabs q crosses the cuts in place of r.
@@ -3489,6 +3554,11 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             if (it + 1 < hint0 && it < maxiter) continue;
             CFD_TRY(finish_to(c, T.blocks, 1, RR_HIST_OFF + (it & 7)));
             if (it < hint0 && it < maxiter) continue;
+            if (spec && it == hint0) {
+                converged_at = it;
+                spec_pending = true;
+                break;
+            }
             double hist[8];
             CFD_TRY(read_scalars2(c, RR_HIST_OFF, 8, hist, CG_OFF_OF(bb), bb < 0.0 ? 1 : 0, &bb));
             if (!(bb == bb)) { set_error("pressure solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
@@ -3527,6 +3597,61 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     }
     *iters = it;
     *relres = bb > 0.0 ? sqrt(rr / bb) : 0.0;
+    if (spec_pending) {
+        Ctx::SpecPcg &sp = c->spec_pcg;
+        double *slot = c->scal + SPEC_PCG_OFF + SPEC_PCG_STRIDE * sp.n;
+        CFD_HIP(hipMemcpyAsync(slot, c->scal + RR_HIST_OFF, 8 * sizeof(double), hipMemcpyDeviceToDevice, st));
+        CFD_HIP(hipMemcpyAsync(slot + 8, c->scal + CG_OFF_OF(bb), sizeof(double), hipMemcpyDeviceToDevice, st));
+        sp.hint[sp.n] = hint0;
+        sp.tol[sp.n] = tol;
+        sp.n += 1;
+        *relres = 0.0;           // known when the iteration's closing read has arrived (spec_verify)
+    }
+    return CFD_OK;
+}
+
+// The stopping tests of a speculative iteration, evaluated on the closing read (Ctx::h_spec = the whole of Ctx::scal).
+// *ok = false: a solve had not converged where its schedule ended -- the caller undoes the iteration and repeats it on the
+// host-checked path.  Fills in what the solves could not know: residual norms of the statistics, res[1], res[2].
+int spec_verify(Ctx *c, double *res, bool *ok) {
+    *ok = true;
+    const double *h = c->h_spec;
+    const Ctx::SpecCheb &sc = c->spec_cheb;
+    if (sc.used) {
+        for (int q = 0; q < sc.nb; ++q) {
+            const double bb = h[SPEC_CHEB_OFF + 2 * sc.nb + q];
+            auto conv = [&](double r2, double margin) { return r2 == r2 && bb == bb && sqrt(r2) <= margin * sc.tol * sqrt(bb); };
+            // the residual history of this right-hand side in iteration order: launch m measured k0 = K (m - 1) and k0 + K - 1
+            double taken = NAN;
+            int earliest = -1;
+            for (int m = 1; m <= sc.launches; ++m) {
+                const int t = sc.t[m - 1][q];
+                if (t < 0) continue;
+                const int off = m == 1 ? SPEC_CHEB_OFF : SPEC_CHEB_OFF + 8 + 4 * (m - 2), na = sc.na[m - 1], k0 = sc.K * (m - 1);
+                const double at[2] = {h[off + t], h[off + na + t]};
+                const int kk[2] = {k0, k0 + sc.K - 1};
+                for (int e = 0; e < 2; ++e) {
+                    if (kk[e] == sc.k[q]) taken = at[e];
+                    if (earliest < 0 && kk[e] < sc.k[q] && conv(at[e], SPEC_MARGIN)) earliest = kk[e];
+                }
+            }
+            if (!conv(taken, 1.0)) { *ok = false; continue; }
+            c->stats.mom_relres[q] = bb > 0.0 ? sqrt(taken / bb) : 0.0;
+            if (res) res[1 + q] = sqrt(taken / global_cells(c));
+            if (earliest >= 0) c->cheb_plan.retire_k[q] = earliest;      // the next replay leaves at the first iterate that was good enough
+        }
+    }
+    const Ctx::SpecPcg &sp = c->spec_pcg;
+    for (int s = 0; s < sp.n; ++s) {
+        const double *slot = h + SPEC_PCG_OFF + SPEC_PCG_STRIDE * s;
+        const double bb = slot[8], rr = slot[sp.hint[s] & 7];
+        if (!(bb == bb) || !(rr == rr) || !(sqrt(rr) <= sp.tol[s] * sqrt(bb))) { *ok = false; continue; }
+        c->stats.p_relres = bb > 0.0 ? sqrt(rr / bb) : 0.0;
+        if (s == sp.n - 1 && sp.hint[s] >= 2) {
+            const double r1 = slot[(sp.hint[s] - 1) & 7];
+            if (r1 == r1 && sqrt(r1) <= sp.tol[s] * sqrt(bb)) c->p_iters_hint = sp.hint[s] - 1;
+        }
+    }
     return CFD_OK;
 }
 

@@ -1249,7 +1249,16 @@ static int finish_continuity(Ctx *c, int nb, double *out, bool with_dt = false) 
     CFD_TRY(reduce_finish(c, 1, 0));
     double s;
     c->dt_host_valid = false;
-    if (with_dt && c->host_lag) {
+    if (c->spec_on) {
+        // speculative iteration: this is its one host read -- everything the solves left in Ctx::scal comes along
+        if (with_dt) CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF, 2, 1));
+        CFD_TRY(read_scalars_all(c));
+        s = c->h_spec[0];
+        if (with_dt) {
+            c->h_dt_ahead[0] = c->h_spec[DT_AHEAD_OFF]; c->h_dt_ahead[1] = c->h_spec[DT_AHEAD_OFF + 1];
+            c->dt_host_valid = true;
+        }
+    } else if (with_dt && c->host_lag) {
         CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF, 2, 1));       // global minimum over the slabs
         CFD_TRY(read_scalars2(c, 0, 1, &s, DT_AHEAD_OFF, 2, c->h_dt_ahead));
         c->dt_host_valid = true;

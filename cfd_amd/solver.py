@@ -595,7 +595,7 @@ def run_case(config):
         if stats["transport_stalled"]:
             import warnings
             warnings.warn(f"{stats['transport_stalled']} transport solve(s) were asked for a tolerance below 1e-12 and "
-                          "stalled between 1e-12 and 1e-10 after two restarts: accepted at the accuracy reached "
+                          "stalled between 1e-12 and 1e-6 after two restarts: accepted at the accuracy reached "
                           "(include/cfd_hip.h: transport_stalled)", RuntimeWarning, stacklevel=2)
     finally:
         dev.close()

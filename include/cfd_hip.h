@@ -96,7 +96,7 @@ typedef struct cfd_solve_stats {
                               * solver.py:829-833; fresh operator: CFD_E_NOCONV like solver.py:842-844).  Transport
                               * solves never end unconverged: CFD_E_NOCONV after a restart with four times maxiter */
     int32_t transport_stalled; /* transport solves since cfd_create that were asked for a tolerance below the rounding
-                              * level of the fp64 recurrences (< 1e-12) and stalled between 1e-12 and 1e-10 after both
+                              * level of the fp64 recurrences (< 1e-12) and stalled between 1e-12 and 1e-6 after both
                               * restarts: accepted as "as far as fp64 goes" and counted here (the host warns); with a
                               * tolerance >= 1e-12 the same stall is CFD_E_NOCONV                                      */
 } cfd_solve_stats;

@@ -539,7 +539,7 @@ def test_correction_fused_into_the_closing_flux_pass(name, tmp_path):
     the same bits in every field; the continuity sum is taken over other strip widths (rounding)."""
     builder, fixup = FUSED_CORRECTION_CASES[name]
     # The turbulent half cylinder blows up in its first step, in the reference as here (nu_t ~ 1e9, dt ~ 1e-15, continuity
-    # ~ 1e6): its k solve, asked for 1e-15, stalls at 7e-12 after 10000 Jacobi-BiCGStab iterations with the default
+    # ~ 1e6): a transport solve of its, asked for 1e-15, stalls at 7e-12 .. 2e-9 after 10000 Jacobi-BiCGStab iterations with the default
     # single-precision multigrid faces (at 1e-13 with double faces: other last bits of p).  Such a stall below the rounding
     # level is accepted and counted (transport_stalled), so the default options run this case too.
     if name == "half_cylinder_komega_132x24":
@@ -606,7 +606,9 @@ def test_fused_correction_at_the_benchmark_size():
         kc = dev.kernel_counts()
         out[fused] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P)], dev.stats(), kc)
         dev.close()
-    assert out[1][2]["correct_flux"] == 6 and out[0][2]["correct_flux"] == 0
+    # (an inner iteration whose speculative replay had to be repeated host-checked launches its kernels twice)
+    assert out[1][2]["correct_flux"] == 6 + out[1][2]["speculative_redone"] and out[0][2]["correct_flux"] == 0
+    assert out[1][2]["speculative_redone"] == out[0][2]["speculative_redone"] <= 1
     for a, b in zip(out[1][0], out[0][0]):
         assert np.array_equal(mask_corners(a), mask_corners(b))
     assert out[1][1]["p_iters"] == out[0][1]["p_iters"] and out[1][1]["mom_iters"] == out[0][1]["mom_iters"]
@@ -634,4 +636,50 @@ def test_odd_levels_scale_coarse_faces_by_the_centre_distance(n):
     for a, b in zip(out[1][0], out[0][0]):
         a, b = mask_corners(a), mask_corners(b)
         scale = max(np.abs(a).max(), 1e-30)
-        assert np.abs(a - b).max() <= 1e-7 * scale, np.abs(a - b).max() / scale
+        # (two preconditioners, solves stopped at 1e-10 relative to |b|: the fields agree to what that leaves in the
+        # smallest field, v; which iterate a solve is taken from also depends on the replayed schedule)
+        assert np.abs(a - b).max() <= 3e-7 * scale, np.abs(a - b).max() / scale
+
+
+def test_speculative_inner_iterations():
+    """Inner iterations that replay the previous iteration's solver schedule with ONE host read at their end (option
+    `speculate`, default on) against the host-checked path: same fields to the solver tolerance, same iteration counts in
+    steady state, <= 3 stream synchronisations per outer step instead of 8 - 11; and a schedule that no longer fits
+    (pressure tolerance tightened between two steps: the replayed count is too short) makes the iteration repeat itself
+    host-checked -- the stopping tests are never skipped."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for spec in (1, 0):
+        dev, ctl, cfg = bench.setup_device(256, False, 2, 1e-8, 0, tuning={"speculate": spec})
+        for step in range(6):
+            advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        kc0 = dev.kernel_counts()
+        dev.host_counters(reset=True)
+        for step in range(6, 12):
+            advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        launches, syncs = dev.host_counters()
+        st = dev.stats()
+        kc1 = dev.kernel_counts()
+        # tighten the pressure tolerance: five iterations are not enough any more
+        dev.set_solver(1e-8, 200, 1e-11, 200, 1e-8, 200, True)
+        advance_one_step(dev, ctl, 12)
+        st2 = dev.stats()
+        kc2 = dev.kernel_counts()
+        out[spec] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P)], st, st2, kc0, kc1, kc2, (syncs - 1) / 6.0)
+        dev.close()
+    f1, st1, st1b, k0, k1, k2, syncs1 = out[1]
+    f0, st0, st0b, _, q1, q2, syncs0 = out[0]
+    assert q2["speculative_iterations"] == 0 and q2["speculative_redone"] == 0
+    assert k1["speculative_iterations"] - k0["speculative_iterations"] == 12 and k1["speculative_redone"] == k0["speculative_redone"]
+    assert syncs1 <= 3.0 < syncs0, (syncs1, syncs0)
+    assert st1["p_iters"] == st0["p_iters"] and st1["mom_iters"] == st0["mom_iters"]
+    assert 0.0 < st1["p_relres"] <= 1e-8 and all(0.0 < r <= 1e-8 for r in st1["mom_relres"])        # filled in by the closing read
+    # the step after the tolerance change: the first replay fails its test and is repeated; both paths end converged
+    assert k2["speculative_redone"] == k1["speculative_redone"] + 1, (k1, k2)
+    assert st1b["p_iters"] == st0b["p_iters"] > st1["p_iters"] and st1b["p_relres"] <= 1e-11
+    for a, b in zip(f1, f0):
+        assert rel_l2(mask_corners(a), mask_corners(b)) <= 1e-7

@@ -32,5 +32,6 @@ for n, turb in ((32, False), (64, False), (128, False), (256, False), (512, Fals
     st = dev.stats()
     print(json.dumps({"n": n, "turbulent": turb, "ms_per_step": round(ms, 3), "ms_mean": round(sum(per_step) / k, 3), "cells_per_s": round(n * n / ms * 1e3),
                       "launches_per_step": round(launches / k, 1), "syncs_per_step": round((syncs - k) / k, 1),
-                      "syncs_by_phase": {k: round(v / k_, 1) for k, v in dev.host_syncs_by_phase().items() if v} if (k_ := k) else {}, "mom_iters": st["mom_iters"], "p_iters": st["p_iters"], "k_iters": st["k_iters"]}), flush=True)
+                      "syncs_by_phase": {k: round(v / k_, 1) for k, v in dev.host_syncs_by_phase().items() if v} if (k_ := k) else {}, "mom_iters": st["mom_iters"], "p_iters": st["p_iters"], "k_iters": st["k_iters"],
+                      "speculative": {q: v for q, v in dev.kernel_counts().items() if q.startswith("speculative")}}), flush=True)
     dev.close()
