@@ -436,7 +436,8 @@ int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, doub
  * face coefficients rounded to single precision -- the Krylov operator stays double, the solution is unchanged),
  * "mg_semi" (1 / 0: stretched meshes are cycled by zebra whole-line relaxation along i with semi-coarsening along j /
  * by the alternating block line smoother with full coarsening; one rank, frozen operator, lines of at most 8192 cells),
- * "probe_capacity" (launches a probe run can time), "mg_v32_emul" (measurement aid), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
+ * "speculate" (-1 / 0 / 1: inner iterations with one host read at their end, see cfd_kernel_counts; auto = contexts of
+ * at most 4M cells), "fuse_correct_slab", "skip_fresh_bc", "probe_capacity" (launches a probe run can time), "mg_v32_emul" (measurement aid), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
  * next pre-smoothing pass / by its own pass).  INTEGRATION.md section 4 has the table.  No counterpart in the reference.     */
 int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
 /* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels
@@ -445,7 +446,10 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
  * than one column strip, [7] tile flux launches, [8] max number of fused multigrid levels in a V-cycle, [9] PCG
  * iterations whose residual update ran inside the pre-smoother, [10] fused PCG direction steps, [11] V-cycles,
  * [12] max number of line-smoothed levels, [13] levels cycled by the single-launch V-cycle tail, [14] launches of the fused
- * correction / flux kernel.  n <= 16 entries are written.  No counterpart in the reference.  */
+ * correction / flux kernel, [15] levels of the semi-coarsened line multigrid, [16] inner iterations that ran speculatively
+ * (option "speculate": solves replay the previous iteration's schedule, one host read at the iteration's end, stopping
+ * tests evaluated then), [17] of those, iterations whose test failed and that were repeated host-checked.
+ * n <= 18 entries are written.  No counterpart in the reference.  */
 int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset);
 /* Host-side cost of the calls so far, process wide: out[0] = kernel launches, out[1] = blocking stream
  * synchronisations the library issued (each one idles the GPU while the host reads a scalar).  They bound the step
