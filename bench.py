@@ -727,10 +727,13 @@ def main():
             # single precision (3 x 8 / 2), the line factors (4 x F / 2: l, 1 / p, and z on periodic lines, 4 B each) and
             # write x (3 x 8 / 2) and the coarse right-hand side (8 / 2): 60 + 2 F; the levels halve, so x 2 per fine
             # cell.  Krylov side per iteration: direction step 64 B (z in double here), residual update 24 B.
+            # With mg_f32 (default) the levels below the finest keep b, x, coarse right-hand side and coarse correction in
+            # single precision: 30 + 2 F per cell there, 56 + 2 F on the finest level.
             fac = 12.0 if args.mesh == "graded" else 8.0
-            per_it = 64.0 + 24.0 + 2.0 * (60.0 + 2.0 * fac)
+            vcycle = (56.0 + 2.0 * fac) + (30.0 + 2.0 * fac) if f32 else 2.0 * (60.0 + 2.0 * fac)
+            per_it = 64.0 + 24.0 + vcycle
             bytes_per_solve = per_it * mean_p_it + 112.0
-            mix = {"semi_coarsened_levels": kcounts["mg_semi_levels"], "vcycle_bytes_per_fine_cell": 2.0 * (60.0 + 2.0 * fac),
+            mix = {"semi_coarsened_levels": kcounts["mg_semi_levels"], "vcycle_bytes_per_fine_cell": vcycle,
                    "krylov_bytes_per_iteration": 88.0, "rhs_pass": 112.0}
             note = ("semi-coarsened line multigrid: algorithmic bytes of a zebra line V(1,1) cycle over all levels + direction step "
                     "+ residual update, x iterations + right-hand side; time = device time of the pressure phase over the two steps "

@@ -129,7 +129,7 @@ if semi:
     fetch = sum(ft[k] for k in semi) * 1024.0 * FACTOR / vc_pmc / cells
     write = sum(wt.get(k, 0.0) for k in semi) * 1024.0 / max(1, sum(wc.get(k, 0) for k in coarsest)) / cells
     us = sum(stats[k][0] * calls[k] for k in semi if k in stats) / max(1, vc_stats)
-    algo = 2.0 * (60.0 + 2.0 * fac)
+    algo = (56.0 + 2.0 * fac) + (30.0 + 2.0 * fac)      # finest level double vectors, coarser levels single (mg_f32 = 1)
     with open(f"profiles/{tag}_pmc8192_bytes_per_cell.csv", "a") as f:
         f.write("# semi-coarsened line multigrid, all k_semi_* launches of one V-cycle (every level), per FINE cell:\n")
         f.write("semi_vcycle;total_B_per_cell;fetch_B_per_cell;write_B_per_cell;algorithmic_B_per_cell;ratio;us_per_vcycle;vcycles_timed;algorithmic_TBps\n")
