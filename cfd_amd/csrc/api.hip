@@ -661,6 +661,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "fuse_correct") c->fuse_correct = iv ? 1 : 0;
     else if (n == "fuse_correct_slab") c->fuse_correct_slab = iv ? 1 : 0;
     else if (n == "skip_fresh_bc") c->skip_fresh_bc = iv ? 1 : 0;
+    else if (n == "semi_fuse_up") c->semi_fuse_up = iv ? 1 : 0;
+    else if (n == "semi_z32") c->semi_z32 = iv ? 1 : 0;
     else if (n == "speculate") c->speculate = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);

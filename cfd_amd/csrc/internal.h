@@ -225,7 +225,7 @@ struct Level {
 struct SemiLevel {
     Geo g;
     double *ci, *cj, *D;          // operator (level 0: the planes of the finest pressure level)
-    double *x, *b;                // levels >= 1
+    double *x, *b, *x2;           // levels >= 1 (x2: the even rows of the way down when the way up is the fused pass)
     float *lmf, *linvf, *cjf;     // single precision: Thomas factors of the whole i-lines (multiplier, inverse pivot), c_j
     float *zf;                    // periodic lines (Sherman-Morrison): T'^-1 u per cell (null: lines are not periodic)
     double *rs;                   // ... and per row {beta / gamma, 1 / (1 + v . z)}
@@ -437,6 +437,10 @@ struct Ctx {
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
     // stretched meshes: zebra whole-line relaxation along i + semi-coarsening along j (semi.inc) in place of the
     // alternating block line smoother; chosen when the finest level's coupling ratio exceeds mg_line_threshold
+    int semi_z32 = 0;                  // semi-coarsened cycle: z handed to the PCG direction step in single precision (with mg_f32).  Off:
+                                       // measured on the 8192-wide stretched meshes it saves 4 % per iteration and costs 0.4 - 0.6
+                                       // iterations per solve (graded 105.9 against 104.7 ms per step, annulus 58.5 against 59.1)
+    int semi_fuse_up = 1;              // semi-coarsened cycle: both colours of the way up in one marching pass on the large levels
     int mg_semi = 1;
     bool semi_on = false;
     std::vector<SemiLevel> semi;

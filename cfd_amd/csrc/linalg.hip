@@ -2913,7 +2913,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     if (z_f32) *z_f32 = false;
     if (c->semi_on) {
         if (rf) { set_error("internal: deferred residual update on a semi-coarsened hierarchy"); return CFD_E_STATE; }
-        CFD_TRY(semi_vcycle(c, r, z0, dot_blocks));
+        const bool z32 = z_f32 && c->mg_f32 && c->semi_z32;      // the caller takes z as a float plane (the PCG direction step does)
+        CFD_TRY(semi_vcycle(c, r, z0, z1 != z0 ? z1 : nullptr, z32, dot_blocks));
+        if (z32) *z_f32 = true;
         *zout = z0;
         return CFD_OK;
     }
