@@ -47,24 +47,26 @@ __device__ __forceinline__ void block_sums(double (&v)[NQ], double *partials) {
     if (tid < NQ) partials[(size_t)tid * MAX_PARTIALS + blockIdx.x] = (sm[tid][0] + sm[tid][1]) + (sm[tid][2] + sm[tid][3]);
 }
 
+// Second stage of every sum: one workgroup of 256 threads, nq <= 8 sums of n partials each.  Per thread a strided run,
+// then wave shuffles, then the four wave sums -- one barrier in all (the first form ran an eight-step LDS tree with a
+// barrier per step for every q: 11 us per call at 8192^2, 34 calls per step, all of them on the critical path).
+// Fixed order: the result does not depend on anything but the partials.
 __global__ void k_sum_finish(const double *partials, int n, int nq, double *out) {
-    __shared__ double sm[256];
+    __shared__ double sm[8][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = 0; q < nq; ++q) {
         double v = 0.0;
-        for (int t = threadIdx.x; t < n; t += 256) v += partials[(size_t)q * MAX_PARTIALS + t];
-        sm[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[q] = sm[0];
-        __syncthreads();
+        for (int t = tid; t < n; t += 256) v += partials[(size_t)q * MAX_PARTIALS + t];
+        v = wsum(v);
+        if (lane == 0) sm[q][wave] = v;
     }
+    __syncthreads();
+    if (tid < nq) out[tid] = (sm[tid][0] + sm[tid][1]) + (sm[tid][2] + sm[tid][3]);
 }
 
 // partials -> out[0..nq), then summed over the slabs of a multi-rank run
 int sum_finish(Ctx *c, const double *partials, int nblocks, int nq, double *out) {
+    if (nq < 1 || nq > 8) { set_error("internal: sum_finish of %d sums", nq); return CFD_E_ARG; }
     hipLaunchKernelGGL(k_sum_finish, dim3(1), dim3(256), 0, c->stream, partials, nblocks, nq, out);
     CFD_HIP(hipGetLastError());
     return all_reduce(c, out, nq, 0);

@@ -81,24 +81,20 @@ __global__ void k_na_weighted_sum(Geo g, const double *f, const double *w, doubl
 }
 // out = {sum f w / sum w, sum f w, sum w}
 __global__ void k_na_finish(const double *partials, int n, double *out) {
-    __shared__ double sm[256];
-    double tot[2];
+    __shared__ double sm[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = 0; q < 2; ++q) {
         double v = 0.0;
-        for (int t = threadIdx.x; t < n; t += 256) v += partials[(size_t)q * MAX_PARTIALS + t];
-        sm[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-            __syncthreads();
-        }
-        tot[q] = sm[0];
-        __syncthreads();
+        for (int t = tid; t < n; t += 256) v += partials[(size_t)q * MAX_PARTIALS + t];
+        v = na_wave_sum(v);
+        if (lane == 0) sm[q][wave] = v;
     }
-    if (threadIdx.x == 0) {
-        out[0] = tot[0] / tot[1];
-        out[1] = tot[0];
-        out[2] = tot[1];
+    __syncthreads();
+    if (tid == 0) {
+        const double a = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), b = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+        out[0] = a / b;
+        out[1] = a;
+        out[2] = b;
     }
 }
 

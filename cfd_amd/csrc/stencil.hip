@@ -469,20 +469,17 @@ __global__ void k_dt(Geo g, MeshDev m, const double *u, const double *v, const d
     }
 }
 
-__global__ void k_min_finish(const double *partials, int n, int nq, double *out) {
-    __shared__ double sm[256];
+__global__ void k_min_finish(const double *partials, int n, int nq, double *out) {      // nq <= 8; shape of k_sum_finish
+    __shared__ double sm[8][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = 0; q < nq; ++q) {
         double v = INFINITY;
-        for (int t = threadIdx.x; t < n; t += 256) v = fmin(v, partials[q * MAX_PARTIALS + t]);
-        sm[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + s]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[q] = sm[0];
-        __syncthreads();
+        for (int t = tid; t < n; t += 256) v = fmin(v, partials[(size_t)q * MAX_PARTIALS + t]);
+        v = wave_min(v);
+        if (lane == 0) sm[q][wave] = v;
     }
+    __syncthreads();
+    if (tid < nq) out[tid] = fmin(fmin(sm[tid][0], sm[tid][1]), fmin(sm[tid][2], sm[tid][3]));
 }
 
 static inline int tiles_of(const Geo &g, int &tx) {
