@@ -663,6 +663,11 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "skip_fresh_bc") c->skip_fresh_bc = iv ? 1 : 0;
     else if (n == "semi_fuse_up") c->semi_fuse_up = iv ? 1 : 0;
     else if (n == "semi_z32") c->semi_z32 = iv ? 1 : 0;
+    else if (n == "fused_min") { if (iv < 4) { set_error("fused_min must be >= 4"); return CFD_E_ARG; } c->fused_min = c->fused_min_cheb = c->fused_min_pcg = c->fused_min_cf = iv; }
+    else if (n == "fused_min_cheb") c->fused_min_cheb = iv < 4 ? 4 : iv;
+    else if (n == "fused_min_pcg") c->fused_min_pcg = iv < 4 ? 4 : iv;
+    else if (n == "fused_min_cf") c->fused_min_cf = iv < 4 ? 4 : iv;
+    else if (n == "tail_from") c->tail_from = iv ? 1 : 0;
     else if (n == "speculate") c->speculate = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);

@@ -437,6 +437,14 @@ struct Ctx {
     int scalar_nu = 0;           // 1: conductances from the scalar nu alone (function-level callers, solver.py:205-207)
     // stretched meshes: zebra whole-line relaxation along i + semi-coarsening along j (semi.inc) in place of the
     // alternating block line smoother; chosen when the finest level's coupling ratio exceeds mg_line_threshold
+    // ... per solver.  The fused Chebyshev form stays at 16: it lets a right-hand side leave at the first iterate that meets
+    // the stopping test, the one-iteration-per-launch form runs to the count its bound predicts (and one more); at the
+    // reference's own rtol of 1e-8 the latter reproduces every printed digit of the committed 5 x 20 friction logs, the
+    // former lands 2e-6 (k-omega) to 5e-6 (SST) away -- for 0.2 ms of a 2.6 ms step.
+    int fused_min_cheb = 16, fused_min_pcg = 4, fused_min_cf = 4;
+    int fused_min = 4;                 // smallest side from which the marching forms of the solvers run (PCG direction step, fused
+                                       // Chebyshev, fused correction): periodic wraps need ni >= the kernel's halo lanes (2)
+    int tail_from = 0;                 // first multigrid level k_mg_tail may start from (0: a small mesh's whole V-cycle in one launch)
     int semi_z32 = 0;                  // semi-coarsened cycle: z handed to the PCG direction step in single precision (with mg_f32).  Off:
                                        // measured on the 8192-wide stretched meshes it saves 4 % per iteration and costs 0.4 - 0.6
                                        // iterations per solve (graded 105.9 against 104.7 ms per step, annulus 58.5 against 59.1)

@@ -2388,7 +2388,7 @@ static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double 
     const Tiling T = tiling(g);
     const dim3 grid(T.blocks), blk = block2d();
     hipStream_t st = c->stream;
-    const bool fused_path = c->mg_fused && g.ni >= 16 && g.nj >= 16;
+    const bool fused_path = c->mg_fused && g.ni >= c->fused_min_cheb && g.nj >= c->fused_min_cheb;
     // the bound of the cached laminar momentum operator is remembered with it
     const bool known = fused_path && op.D == c->ap && c->ap_cached && c->rho_cached >= 0.0;
     if (!known) {
@@ -2789,7 +2789,11 @@ int build_pressure_hierarchy(Ctx *c) {
         for (int l = 0; l < nl; ++l)
             if (c->levels[l].line) last_line = l;
         if (c->mg_tail && nl > 1) {
-            for (int lt = std::max(1, std::max(la, last_line + 1)); lt < nl; ++lt) {
+            // From level 0 on a mesh too small for the fused marching kernels (a side below 16 cells: the reference's own
+            // cases are 5 x 20 ... 15 x 40): the whole V-cycle is then ONE launch instead of eight kernels of the
+            // one-sweep-per-launch form around the tail.  tail_from = 1 keeps the finest level out.
+            const int lt0 = (c->tail_from == 0 && !level_fusable(c, 0, c->levels[0].g, coarse_view(c, 1))) ? 0 : 1;
+            for (int lt = std::max(lt0, std::max(la, last_line + 1)); lt < nl; ++lt) {
                 long total = 0;
                 for (int l = lt; l < nl; ++l) total += (long)c->levels[l].g.ni * c->levels[l].g.nj;
                 const long top = (long)c->levels[lt].g.ni * c->levels[lt].g.nj;
@@ -2818,7 +2822,7 @@ int build_pressure_hierarchy(Ctx *c) {
     // solution of the double-precision operator as before, and each fused pass reads 8 B per cell less.
     {
         const int nl = (int)c->levels.size();
-        const int n_top = c->tail_lt > 0 ? c->tail_lt : nl - 1;
+        const int n_top = c->tail_lt >= 0 ? c->tail_lt : nl - 1;
         size_t need = 0;
         std::vector<char> want(nl, 0);
         for (int l = 0; l < nl; ++l) {
@@ -2947,7 +2951,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     c->kc[KC_VCYCLE] += 1;
     int n_fused_levels = 0;
     const int lt = c->tail_lt;                   // levels [lt, nl) are cycled by k_mg_tail in one launch
-    const int n_top = lt > 0 ? lt : nl - 1;      // levels [0, n_top) run their own kernels
+    const int n_top = lt >= 0 ? lt : nl - 1;     // levels [0, n_top) run their own kernels
     for (int l = 0; l < n_top; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
@@ -3037,7 +3041,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         }
         if (to_agg) CFD_TRY(all_gather_rows(c, cb + NG * (size_t)cg.pitch, C.b + NG * (size_t)cg.pitch, (size_t)cg.nj * cg.pitch));
     }
-    if (lt > 0) {
+    if (lt >= 0) {
         TailArgs a = c->tail;
         a.per_i = c->pp_per_i; a.per_j = c->pp_per_j; a.pre = pre; a.post = post; a.coarse_sweeps = c->mg_coarse_sweeps;
         a.nom = c->mg_nom < 4 ? c->mg_nom : 4;
@@ -3394,7 +3398,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     CgScal *S = reinterpret_cast<CgScal *>(c->scal + CG_OFF);
     double *r = c->kry[1], *p = c->kry[2], *q = c->kry[3], *za = c->kry[4], *zb = c->kry[5];
     // fused direction step: marching kernel, p ping-pongs between two planes
-    const bool fused = c->mg_fused && g.ni >= 16 && g.nj >= 16;
+    const bool fused = c->mg_fused && g.ni >= c->fused_min_pcg && g.nj >= c->fused_min_pcg;
     double *pbuf[2] = {c->kry[2], c->kry[6]};
     MarchGeo mgeo = march_geo(g);
     mgeo.nstrips = (g.ni + 61) / 62;

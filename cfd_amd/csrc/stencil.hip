@@ -1269,7 +1269,7 @@ static int finish_continuity(Ctx *c, int nb, double *out, bool with_dt = false) 
 // Host side of k_correct_flux: can this context take the fused pass, and the launch.
 bool correct_flux_ok(const Ctx *c) {
     if (!c->fuse_correct || !c->march_flux || !c->rhs_lookahead) return false;
-    if (c->per_j || c->pp_per_j || c->g.ni < 8 || c->g.nj < 4) return false;
+    if (c->per_j || c->pp_per_j || c->g.ni < c->fused_min_cf || c->g.nj < 4) return false;
     // every rank of a slab run must decide alike (the pass has its own exchanges): fuse_correct_slab is set by
     // cfd_set_flow_bc_tables' callers only through options, the side classes of the cut sides do not matter
     if (c->comm.nranks > 1 && !c->fuse_correct_slab) return false;
