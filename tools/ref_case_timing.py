@@ -35,8 +35,15 @@ def gpu_run(model, n_steps):
 
 for model in ("k_omega", "sst"):
     gpu_run(model, 20)                         # library load, first use of every kernel
+    import ctypes as C
+    from cfd_amd import _lib
+    lib = _lib.load()
+    cnt = (C.c_longlong * 2)()
     w1, s1, mp = gpu_run(model, 100)
+    lib.cfd_host_counters(cnt, 1)
     w2, s2, mp = gpu_run(model, 100 + steps)
+    lib.cfd_host_counters(cnt, 0)
+    print(f"     launches per step {cnt[0] / s2:.0f}, stream synchronisations per step {cnt[1] / s2:.1f}")
     kc = hip_solver.LAST_RUN["kernel_counts"]
     print(f"GPU  {model:8s} {mp['count_i']}x{mp['count_j']}  {1e3 * (w2 - w1) / (s2 - s1):.3f} ms/step (difference of a {s2}- and a {s1}-step run_case)  "
           f"semi_levels {kc['mg_semi_levels']} line_levels {kc['mg_line_levels_max']} spec {kc['speculative_iterations']}/{kc['speculative_redone']} "
