@@ -151,7 +151,7 @@ static size_t workspace_bytes_impl(int ni, int nj, int nranks, int min_rows, siz
     if (nranks > 1) total += 3 * align256(gs.plane_elems() * sizeof(double));
     // single-precision copies of the face planes of every multigrid level (option mg_f32, on by default)
     for (size_t l = 0; l < lv.size(); ++l) total += 2 * align256(lv[l].plane_elems() * sizeof(float));
-    total += MISC_BYTES + bc_bytes + 4096;
+    total += MISC_BYTES + bc_bytes + 4096 + 2 * TAIL_TABLE_BYTES;
     return total;
 }
 
@@ -303,6 +303,7 @@ int cfd_create_slab(cfd_ctx **out, int ni, int nj, int device, void *workspace, 
         c->f32_mem = (char *)cv.take(fb);
         c->f32_mem_bytes = c->f32_mem ? fb : 0;
     }
+    c->tail_tab = (double *)cv.take(2 * TAIL_TABLE_BYTES);
     c->partials = (double *)cv.take((size_t)8 * MAX_PARTIALS * sizeof(double));
     c->scal = (double *)cv.take(2048);
     c->bc_buf = (char *)cv.take(bc_bytes_for(ni, nj));
@@ -668,6 +669,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "fused_min_pcg") c->fused_min_pcg = iv < 4 ? 4 : iv;
     else if (n == "fused_min_cf") c->fused_min_cf = iv < 4 ? 4 : iv;
     else if (n == "tail_from") c->tail_from = iv ? 1 : 0;
+    else if (n == "pcg_tail") { c->pcg_tail = iv ? 1 : 0; c->p_built = false; }
+    else if (n == "pcg_tail_cells") { if (iv < 0 || iv > TAIL_MAX_CELLS) { set_error("pcg_tail_cells: 0 .. %d", TAIL_MAX_CELLS); return CFD_E_ARG; } c->pcg_tail_cells = iv; c->p_built = false; }
     else if (n == "speculate") c->speculate = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);

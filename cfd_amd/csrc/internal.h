@@ -196,7 +196,7 @@ __device__ __forceinline__ void store_stream_f32(float *p, float v, int nt) {
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
-    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_SPEC_ITERS, KC_SPEC_REDONE, KC_COUNT = 18
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_SPEC_ITERS, KC_SPEC_REDONE, KC_PCG_TAIL, KC_COUNT = 19
 };
 
 // ------------------------------------------------------------------ multigrid level
@@ -237,17 +237,39 @@ constexpr int TAIL_CPT = 4;                         // cells per thread on the l
 constexpr int TAIL_MAX_CELLS = TAIL_NT * TAIL_CPT;
 constexpr int TAIL_MAX_LEVELS = 12;
 constexpr int TAIL_LDS_DOUBLES = 20480;             // 160 KiB, what one gfx950 workgroup may declare
+// LDS doubles of a tail: x and b of every level, a scratch plane of the largest, six coupling planes and two int planes
+// of the cached levels
+constexpr size_t TAIL_TABLE_BYTES = (size_t)(TAIL_MAX_CELLS + 2 * TAIL_NT) * 64;      // k_tail_pack's table: 60 bytes per tail cell (the workspace holds two)
+inline long tail_lds_doubles(long total, long top, long ncache) { return 2 * total + top + 7 * ncache; }
+// ... of a whole solve (k_pcg_tail): p, the diagonal and x of the finest level, reduction slots
+inline long pcg_tail_lds_doubles(long total, long top, long ncache) { return tail_lds_doubles(total, top, ncache) + 3 * top + 40; }
 struct TailLevel {
     const double *ci, *cj, *D;
     Geo g;
     int fi, fj;          // coarsening factors towards the next level
     int off;             // offset of this level's x and b inside the LDS arrays
+    int coff;            // levels 2 ..: offset of this level's couplings inside the LDS cache
 };
 struct TailArgs {
     TailLevel L[TAIL_MAX_LEVELS];
     int n, total;        // levels, sum of their cells
+    int ncache;          // cells of levels 2 .. (their couplings are cached in LDS)
+    const double *tab;   // the couplings of every tail cell, packed by k_tail_pack
     int per_i, per_j, pre, post, coarse_sweeps, nom;
     double om[4], om_coarse, gamma;
+};
+// what the cycle itself needs of a tail, small enough to arrive with the first lines of the kernel arguments
+// (the cycle reads no plane: the couplings come packed from TailArgs::tab)
+struct TailDevLevel {
+    int ni, nj, off, coff;
+};
+struct TailDev {
+    int n, total, ncache;
+    int per_i, per_j, pre, post, coarse_sweeps, nom;
+    double om[4], om_coarse, gamma;
+    const double *tab;
+    Geo g0;              // plane geometry of the first tail level (right-hand side in, result out)
+    TailDevLevel L[TAIL_MAX_LEVELS];
 };
 
 // j-slab communication: callbacks supplied by the host (torch.distributed over RCCL in
@@ -472,6 +494,11 @@ struct Ctx {
     bool bb_ready = false;       // scal[83] holds (b, b) of the pressure right-hand side just built (launch_pressure_rhs)
     int plane_swap = 1;          // the Chebyshev result plane becomes u* / v* / k / omega by rebinding pointers, not by a copy
     int mg_tail = 1;             // 1: levels that fit one workgroup's LDS are cycled by one launch
+    double *tail_tab = nullptr;  // 2 x TAIL_TABLE_BYTES of the workspace: the V-cycle tail's table, the whole-solve tail's
+    TailArgs ptail{};            // the hierarchy from level 0 for k_pcg_tail (the whole MG-PCG solve in one launch)
+    bool ptail_ok = false;
+    int pcg_tail = 1;            // 1: meshes of at most pcg_tail_cells cells whose hierarchy fits one workgroup's LDS solve p' in one launch
+    int pcg_tail_cells = 1024;
     int tail_lt = -1;            // first level of the tail (-1: none), set when the hierarchy is built
     TailArgs tail{};
     double *sst_S = nullptr, *sst_F1 = nullptr, *sst_F2 = nullptr, *sst_Dk = nullptr, *sst_Dw = nullptr, *sst_dw = nullptr;

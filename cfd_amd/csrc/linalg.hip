@@ -643,155 +643,559 @@ __global__ void k_mg_coarsest(OpDev op, const double *b, double omega, int sweep
 
 
 // ------------------------------------------------------------------ V-cycle tail in one workgroup
-// Levels lt .. nl-1 of the hierarchy (at most TAIL_MAX_CELLS cells on the largest) are cycled by a single
-// workgroup: x and b of every tail level stay in LDS, a thread keeps the couplings of its (at most TAIL_CPT)
-// cells of the level being worked on in registers, the phases are separated by workgroup barriers.  Replaces,
-// per V-cycle, two launches per fused level, eight per unfused level and the coarsest-level kernel -- all of them
-// far below the size at which a launch is worth its latency.  Arithmetic: that of k_mg_first / k_mg_jacobi /
-// k_mg_restrict / k_mg_prolong / k_mg_coarsest (same expressions, same order).
-__global__ __launch_bounds__(TAIL_NT) void k_mg_tail(TailArgs a, const double *b0, double *x0) {
-    extern __shared__ double lds[];              // 2 * total + cells of the largest level, sized by the launch
-    double *X = lds, *B = lds + a.total, *T = lds + 2 * a.total;
-    const int tid = threadIdx.x;
-    double cw[TAIL_CPT], ce[TAIL_CPT], cs[TAIL_CPT], cn[TAIL_CPT], dg[TAIL_CPT];
-    int iw[TAIL_CPT], ie[TAIL_CPT], is[TAIL_CPT], in[TAIL_CPT];
-    int ni = 0, nj = 0, n = 0;
-    // couplings and neighbour slots of this thread's cells of level t (boundary couplings without a neighbour: zero)
-    auto load_level = [&](int t) {
-        const TailLevel &L = a.L[t];
-        ni = L.g.ni; nj = L.g.nj; n = ni * nj;
-#pragma unroll
-        for (int q = 0; q < TAIL_CPT; ++q) {
-            const int idx = tid + q * TAIL_NT;
-            cw[q] = ce[q] = cs[q] = cn[q] = 0.0; dg[q] = 0.0;
-            iw[q] = ie[q] = is[q] = in[q] = 0;
-            if (idx < n) {
-                const int i = idx % ni, j = idx / ni;
-                const size_t c = L.g.cell(i, j), P = L.g.pitch;
-                dg[q] = L.D[c];
-                iw[q] = ie[q] = is[q] = in[q] = idx;
-                if (i > 0) { cw[q] = L.ci[c]; iw[q] = idx - 1; }
-                else if (a.per_i) { cw[q] = L.ci[c]; iw[q] = idx + (ni - 1); }
-                if (i < ni - 1) { ce[q] = L.ci[c + 1]; ie[q] = idx + 1; }
-                else if (a.per_i) { ce[q] = L.ci[c + 1]; ie[q] = idx - (ni - 1); }
-                if (j > 0) { cs[q] = L.cj[c]; is[q] = idx - ni; }
-                else if (a.per_j) { cs[q] = L.cj[c]; is[q] = idx + (nj - 1) * ni; }
-                if (j < nj - 1) { cn[q] = L.cj[c + P]; in[q] = idx + ni; }
-                else if (a.per_j) { cn[q] = L.cj[c + P]; in[q] = idx - (nj - 1) * ni; }
-            }
-        }
-    };
-    // (A x) at slot q of the loaded level
-    auto apply = [&](const double *x, int q, int idx) {
-        double s = 0.0;
-        s += cw[q] * x[iw[q]];
-        s += ce[q] * x[ie[q]];
-        s += cs[q] * x[is[q]];
-        s += cn[q] * x[in[q]];
-        return dg[q] * x[idx] - s;
-    };
-    auto first = [&](const double *b, double om, double *x, bool guard) {
-#pragma unroll
-        for (int q = 0; q < TAIL_CPT; ++q) {
-            const int idx = tid + q * TAIL_NT;
-            if (idx < n) x[idx] = (!guard || dg[q] > 0.0) ? om * b[idx] / dg[q] : 0.0;
-        }
-        __syncthreads();
-    };
-    auto jacobi = [&](const double *b, const double *x, double om, double *xn, bool guard) {
-#pragma unroll
-        for (int q = 0; q < TAIL_CPT; ++q) {
-            const int idx = tid + q * TAIL_NT;
-            if (idx < n) {
-                const double ax = apply(x, q, idx);
-                xn[idx] = (!guard || dg[q] > 0.0) ? x[idx] + om * (b[idx] - ax) / dg[q] : 0.0;
-            }
-        }
-        __syncthreads();
-    };
-    const int nt = a.n;
-    // right-hand side of the first tail level: from its plane in global memory
-    {
-        const TailLevel &L = a.L[0];
-        const int n0 = L.g.ni * L.g.nj;
-        for (int idx = tid; idx < n0; idx += TAIL_NT) B[idx] = b0[L.g.cell(idx % L.g.ni, idx / L.g.ni)];
+// Levels lt .. nl-1 of the hierarchy (at most TAIL_MAX_CELLS cells on the largest, TAIL_NT on each of the others) are
+// cycled by a single workgroup: x and b of every tail level stay in LDS, the phases are separated by workgroup barriers.
+// Replaces, per V-cycle, two launches per fused level, eight per unfused level and the coarsest-level kernel -- all of
+// them far below the size at which a launch is worth its latency.
+//   Where the time of that one workgroup goes decided the layout (tools/tail_clocks.py: 41.7 us per cycle from 64^2
+//   before, of which 18 on the 4096-cell level -- arithmetic of ONE compute unit, a double-precision division per cell
+//   and sweep -- 7.6 in the 39 barriers of the coarsest level, 5 waiting for coefficient loads level by level):
+//   * the couplings of the first two tail levels are loaded once and stay in registers (TailSet<4>, TailSet<1>), those of
+//     the smaller levels are fetched once into LDS; nothing is read from global memory after the prologue;
+//   * a sweep is x' = (1 - w) x + (w / D)(b + sum c x_nb) with 1 / D formed at load time (the same damped Jacobi step
+//     as k_mg_jacobi, in a form without a division; the V-cycle only has to be one fixed symmetric operator, it does not
+//     have to round like the multi-launch cycle);
+//   * neighbour slots follow from four boundary flags per cell, parent / child slots of the transfers are formed at load
+//     time: no integer division inside the cycle;
+//   * levels of at most 64 cells are cycled by wave 0 alone, which needs no workgroup barrier (LDS operations of one
+//     wave execute in order); the other waves wait at the one barrier that ends that section.
+#ifdef TAIL_CLOCKS
+// (instrumented build of tools/tail_clocks.py only: 100 MHz timestamps of the phases of one launch)
+__device__ unsigned long long g_tail_clk[256];
+struct TailMark {
+    int n = 0;
+    __device__ __forceinline__ void operator()() { if (threadIdx.x == 0 && n < 255) g_tail_clk[n++] = wall_clock64(); }
+};
+#else
+struct TailMark {
+    __device__ __forceinline__ void operator()() const {}
+};
+#endif
+
+template <int S>
+struct TailSet {
+    // (the four-slot set of the first level keeps no diagonal: only the residual needs it, and takes it from the table)
+    double cw[S], ce[S], cs[S], cn[S], dg[S == 1 ? 1 : 0 + 1], inv[S];
+    int fl[S];           // 1: i == 0, 2: i == ni - 1, 4: j == 0, 8: j == nj - 1, 16 / 32: the aggregate has a second column / row;
+                         // from bit 6: slot of the parent cell on the next level
+    int ch[S == 1 ? 1 : 0 + 1];   // slot of the first child on the previous level (never asked of the first level)
+    int n, ni, dwi, dsj; // cells, row length, what a neighbour slot moves by across the i / j boundary
+    static constexpr int slots = S;
+};
+struct TailLds {
+    double *X, *B, *T, *CF;
+    int *CFI;
+    int ncache;
+};
+__device__ __forceinline__ TailLds tail_lds(const TailDev &a, double *lds) {
+    TailLds m;
+    const int n0 = a.L[0].ni * a.L[0].nj;
+    m.X = lds; m.B = lds + a.total; m.T = lds + 2 * a.total;
+    m.CF = m.T + n0;
+    m.ncache = a.ncache;
+    m.CFI = reinterpret_cast<int *>(m.CF + 6 * a.ncache);
+    return m;
+}
+template <bool WAVE>
+__device__ __forceinline__ void tail_sync() {
+    if (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
         __syncthreads();
     }
-    // ---- down: pre-smoothing from a zero guess, residual, restriction
-    for (int t = 0; t < nt - 1; ++t) {
-        load_level(t);
-        double *xt = X + a.L[t].off, *bt = B + a.L[t].off;
-        // the pre-smoothed x must end in xt: start in xt for an odd number of sweeps, in T otherwise
-        double *cur = (a.pre & 1) ? xt : T, *oth = (a.pre & 1) ? T : xt;
-        first(bt, a.om[0], cur, false);
-        for (int s = 1; s < a.pre; ++s) {
-            jacobi(bt, cur, a.om[s % a.nom], oth, false);
-            double *tmp = cur; cur = oth; oth = tmp;
-        }
-        // residual into T, then one thread per coarse cell sums its aggregate
+}
+// couplings of cell idx of tail level t as the cycle uses them (boundary couplings without a neighbour: zero), from the planes
+struct TailCell {
+    double cw, ce, cs, cn, dg, inv;
+    int fl, par, ch;
+};
+__device__ __forceinline__ TailCell tail_cell(const TailArgs &a, int t, int idx) {
+    const TailLevel &L = a.L[t];
+    const int ni = L.g.ni, nj = L.g.nj;
+    const int i = idx % ni, j = idx / ni;
+    const size_t c = L.g.cell(i, j), P = L.g.pitch;
+    // (every address is inside the plane: faces ni and nj exist, whatever bounds them)
+    const double d = L.D[c], w = L.ci[c], e = L.ci[c + 1], s = L.cj[c], nn = L.cj[c + P];
+    TailCell r;
+    r.fl = (i == 0 ? 1 : 0) | (i == ni - 1 ? 2 : 0) | (j == 0 ? 4 : 0) | (j == nj - 1 ? 8 : 0);
+    r.cw = (!(r.fl & 1) || a.per_i) ? w : 0.0;
+    r.ce = (!(r.fl & 2) || a.per_i) ? e : 0.0;
+    r.cs = (!(r.fl & 4) || a.per_j) ? s : 0.0;
+    r.cn = (!(r.fl & 8) || a.per_j) ? nn : 0.0;
+    r.dg = d;
+    r.inv = d > 0.0 ? 1.0 / d : 0.0;
+    r.par = 0;
+    r.ch = 0;
+    if (t + 1 < a.n) r.par = (j >> (L.fj - 1)) * a.L[t + 1].g.ni + (i >> (L.fi - 1));
+    if (t > 0) {
+        const TailLevel &F = a.L[t - 1];
+        const int i0 = i << (F.fi - 1), j0 = j << (F.fj - 1);
+        r.ch = j0 * F.g.ni + i0;
+        if (F.fi == 2 && i0 + 1 < F.g.ni) r.fl |= 16;
+        if (F.fj == 2 && j0 + 1 < F.g.nj) r.fl |= 32;
+    }
+    return r;
+}
+// The couplings of every tail cell as the cycle uses them, packed once per hierarchy (build_pressure_hierarchy) into a
+// table of six double and two int arrays over the concatenated levels: the cycle's prologue is then plain coalesced
+// loads, without index arithmetic, branches or divisions.
+__global__ void k_tail_pack(TailArgs a, double *tab) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.total) return;
+    int t = 0, idx = k;
+    while (t < a.n - 1 && idx >= a.L[t].g.ni * a.L[t].g.nj) { idx -= a.L[t].g.ni * a.L[t].g.nj; ++t; }
+    const TailCell r = tail_cell(a, t, idx);
+    const int nt = a.total;
+    tab[k] = r.cw; tab[nt + k] = r.ce; tab[2 * nt + k] = r.cs; tab[3 * nt + k] = r.cn; tab[4 * nt + k] = r.dg; tab[5 * nt + k] = r.inv;
+    int *ti = reinterpret_cast<int *>(tab + 6 * (size_t)nt);
+    ti[k] = r.fl | (r.par << 6);
+    ti[nt + k] = r.ch;
+}
+template <int S>
+__device__ __forceinline__ void tail_set_geo(const TailDev &a, int t, TailSet<S> &s) {
+    s.ni = a.L[t].ni;
+    s.n = a.L[t].ni * a.L[t].nj;
+    s.dwi = a.per_i ? s.ni : 1;
+    s.dsj = a.per_j ? s.n : s.ni;
+}
+// (uniform base + 32-bit byte offset: one address register per slot instead of a 64-bit pointer per load)
+template <typename T>
+__device__ __forceinline__ T tail_ld(const void *base, unsigned byte_off) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+// (slots beyond the level's cells hold the couplings of some cell: every use is guarded by idx < n)
+template <int S>
+__device__ __forceinline__ void tail_load_table(const TailDev &a, int t, TailSet<S> &s, int tid) {
+    tail_set_geo(a, t, s);
+    const int nt = a.total;
+    const double *t1 = a.tab + nt, *t2 = a.tab + 2 * nt, *t3 = a.tab + 3 * nt, *t4 = a.tab + 4 * nt, *t5 = a.tab + 5 * nt;
+    const int *ti = reinterpret_cast<const int *>(a.tab + 6 * (size_t)nt), *tj = ti + nt;
+    if (S > 1) s.dg[0] = 0.0, s.ch[0] = 0;
 #pragma unroll
-        for (int q = 0; q < TAIL_CPT; ++q) {
+    for (int q = 0; q < S; ++q) {
+        const int idx = tid + q * TAIL_NT;
+        const unsigned k = (unsigned)(a.L[t].off + (idx < s.n ? idx : 0));
+        s.cw[q] = tail_ld<double>(a.tab, k * 8u); s.ce[q] = tail_ld<double>(t1, k * 8u); s.cs[q] = tail_ld<double>(t2, k * 8u);
+        s.cn[q] = tail_ld<double>(t3, k * 8u); s.inv[q] = tail_ld<double>(t5, k * 8u);
+        if (S == 1) s.dg[q] = tail_ld<double>(t4, k * 8u);
+        s.fl[q] = tail_ld<int>(ti, k * 4u);
+        if (S == 1) s.ch[q] = tail_ld<int>(tj, k * 4u);
+    }
+}
+// levels 2 .. of the tail: their part of the table is copied into LDS, from where tail_load_cache takes a level's
+// couplings whenever the cycle comes to it
+__device__ __forceinline__ void tail_fill_cache(const TailDev &a, const TailLds &m, int tid) {
+    if (tid >= m.ncache) return;
+    const int nt = a.total, nc = m.ncache;
+    const unsigned k = (unsigned)(a.L[2].off + tid);
+    const int *ti = reinterpret_cast<const int *>(a.tab + 6 * (size_t)nt);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) m.CF[c * nc + tid] = tail_ld<double>(a.tab + c * nt, k * 8u);
+    m.CFI[tid] = tail_ld<int>(ti, k * 4u);
+    m.CFI[nc + tid] = tail_ld<int>(ti + nt, k * 4u);
+}
+__device__ __forceinline__ void tail_load_cache(const TailDev &a, const TailLds &m, int t, TailSet<1> &s, int tid) {
+    tail_set_geo(a, t, s);
+    const int nc = m.ncache, k = a.L[t].coff + (tid < s.n ? tid : 0);
+    s.cw[0] = m.CF[k]; s.ce[0] = m.CF[nc + k]; s.cs[0] = m.CF[2 * nc + k]; s.cn[0] = m.CF[3 * nc + k];
+    s.dg[0] = m.CF[4 * nc + k]; s.inv[0] = m.CF[5 * nc + k];
+    s.fl[0] = m.CFI[k];
+    s.ch[0] = m.CFI[nc + k];
+}
+// (the cycle's arithmetic may contract into fused multiply-adds: nothing here has to round like the reference)
+#pragma clang fp contract(fast)
+// sum of c x over the four neighbours of slot q
+template <typename SET>
+__device__ __forceinline__ double tail_nbr(const SET &s, int q, int idx, const double *x) {
+    int f = s.fl[q];
+    if (SET::slots > 1) asm volatile("" : "+v"(f));      // (as tail_slot: the four boundary offsets of a slot are formed where they are used, not kept)
+    const int iw = idx - 1 + ((f & 1) ? s.dwi : 0), ie = idx + 1 - ((f & 2) ? s.dwi : 0);
+    const int is = idx - s.ni + ((f & 4) ? s.dsj : 0), in = idx + s.ni - ((f & 8) ? s.dsj : 0);
+    double acc = s.cw[q] * x[iw];
+    acc += s.ce[q] * x[ie];
+    acc += s.cs[q] * x[is];
+    acc += s.cn[q] * x[in];
+    return acc;
+}
+// a four-slot set leaves few registers for the sweep itself: one slot's loads and arithmetic at a time (the other three
+// waves of the SIMD cover the latency), instead of all twenty loads hoisted to the top and their values spilled
+// (the slot's cell index is formed anew in every sweep: hoisted out of the sweep loops, the LDS addresses of the twenty
+// neighbours would be registers the coupling sets need)
+template <typename SET>
+__device__ __forceinline__ int tail_slot(int tid, int q) {
+    int idx = tid + q * TAIL_NT;
+    if (SET::slots > 1) asm volatile("" : "+v"(idx));      // (a one-slot set has the registers: its addresses may stay)
+    return idx;
+}
+#define TAIL_SLOT_FENCE(SET) do { if (SET::slots > 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+template <bool WAVE, typename SET>
+__device__ __forceinline__ void tail_first(const SET &s, const double *b, double om, double *x, int tid) {
+#pragma unroll
+    for (int q = 0; q < SET::slots; ++q) {
+        const int idx = tail_slot<SET>(tid, q);
+        if (idx < s.n) x[idx] = (om * s.inv[q]) * b[idx];
+        TAIL_SLOT_FENCE(SET);
+    }
+    tail_sync<WAVE>();
+}
+template <bool WAVE, typename SET>
+__device__ __forceinline__ void tail_jacobi(const SET &s, const double *b, const double *x, double om, double *xn, int tid) {
+    const double keep = 1.0 - om;
+#pragma unroll
+    for (int q = 0; q < SET::slots; ++q) {
+        const int idx = tail_slot<SET>(tid, q);
+        if (idx < s.n) xn[idx] = keep * x[idx] + (om * s.inv[q]) * (b[idx] + tail_nbr(s, q, idx, x));
+        TAIL_SLOT_FENCE(SET);
+    }
+    tail_sync<WAVE>();
+}
+// where the result of level t ends (x of the level or the scratch plane): the same for every wave, whether or not it took part
+__device__ __forceinline__ double *tail_result(const TailDev &a, const TailLds &m, int t) {
+    const int swaps = (t == a.n - 1) ? a.coarse_sweeps - 1 : a.post;
+    return (swaps & 1) ? m.T : m.X + a.L[t].off;
+}
+// pre-smoothing from a zero guess, residual into the scratch plane
+template <bool WAVE, typename SET>
+__device__ __forceinline__ void tail_down(const TailDev &a, const TailLds &m, int t, const SET &s, int tid) {
+    double *xt = m.X + a.L[t].off, *bt = m.B + a.L[t].off;
+    // the diagonal of a four-slot set: asked for now, there when the residual is formed
+    double dgq[SET::slots];
+#pragma unroll
+    for (int q = 0; q < SET::slots; ++q) {
+        if (SET::slots > 1) {
             const int idx = tid + q * TAIL_NT;
-            if (idx < n) T[idx] = bt[idx] - apply(xt, q, idx);
+            dgq[q] = tail_ld<double>(a.tab + 4 * a.total, (unsigned)(a.L[t].off + (idx < s.n ? idx : 0)) * 8u);
+        } else {
+            dgq[q] = s.dg[q];
         }
-        __syncthreads();
-        const TailLevel &C = a.L[t + 1];
-        const int fi = a.L[t].fi, fj = a.L[t].fj, nic = C.g.ni, nc = C.g.ni * C.g.nj;
-        double *bc = B + C.off;
-        for (int idc = tid; idc < nc; idc += TAIL_NT) {
-            const int i = idc % nic, j = idc / nic;
-            double s = 0.0;
-            for (int dj = 0; dj < fj; ++dj) {
-                const int jf = j * fj + dj;
-                if (jf >= nj) break;
-                for (int di = 0; di < fi; ++di) {
-                    const int ifn = i * fi + di;
-                    if (ifn >= ni) break;
-                    s += T[jf * ni + ifn];
+    }
+    // the pre-smoothed x must end in xt: start in xt for an odd number of sweeps, in T otherwise
+    double *cur = (a.pre & 1) ? xt : m.T, *oth = (a.pre & 1) ? m.T : xt;
+    tail_first<WAVE>(s, bt, a.om[0], cur, tid);
+    for (int k = 1; k < a.pre; ++k) {
+        tail_jacobi<WAVE>(s, bt, cur, a.om[k % a.nom], oth, tid);
+        double *tmp = cur; cur = oth; oth = tmp;
+    }
+#pragma unroll
+    for (int q = 0; q < SET::slots; ++q) {
+        const int idx = tail_slot<SET>(tid, q);
+        if (idx < s.n) m.T[idx] = (bt[idx] - dgq[q] * xt[idx]) + tail_nbr(s, q, idx, xt);
+        TAIL_SLOT_FENCE(SET);
+    }
+    tail_sync<WAVE>();
+}
+// right-hand side of level t >= 1: the residual of level t - 1 (in the scratch plane) summed over the aggregate
+template <bool WAVE>
+__device__ __forceinline__ void tail_restrict(const TailDev &a, const TailLds &m, int t, const TailSet<1> &s, int tid) {
+    if (tid < s.n) {
+        const int nif = a.L[t - 1].ni, c0 = s.ch[0], f = s.fl[0];
+        double v = m.T[c0];
+        if (f & 16) v += m.T[c0 + 1];
+        if (f & 32) {
+            v += m.T[c0 + nif];
+            if (f & 16) v += m.T[c0 + nif + 1];
+        }
+        m.B[a.L[t].off + tid] = v;
+    }
+    // the level's first sweep writes x of the level, or (even number of sweeps) the scratch plane that was just read
+    if (!(a.pre & 1) && t < a.n - 1) tail_sync<WAVE>();
+}
+template <bool WAVE, typename SET>
+__device__ __forceinline__ void tail_coarsest(const TailDev &a, const TailLds &m, int t, const SET &s, int tid) {
+    double *cur = m.X + a.L[t].off, *oth = m.T, *bt = m.B + a.L[t].off;
+    tail_first<WAVE>(s, bt, a.om_coarse, cur, tid);
+    for (int k = 1; k < a.coarse_sweeps; ++k) {
+        tail_jacobi<WAVE>(s, bt, cur, a.om_coarse, oth, tid);
+        double *tmp = cur; cur = oth; oth = tmp;
+    }
+}
+// coarse correction of level t + 1 added, post-smoothing
+template <bool WAVE, typename SET>
+__device__ __forceinline__ void tail_up(const TailDev &a, const TailLds &m, int t, const SET &s, int tid) {
+    const double *e = tail_result(a, m, t + 1);
+    double *xt = m.X + a.L[t].off, *bt = m.B + a.L[t].off;
+#pragma unroll
+    for (int q = 0; q < SET::slots; ++q) {
+        const int idx = tail_slot<SET>(tid, q);
+        if (idx < s.n) xt[idx] += a.gamma * e[s.fl[q] >> 6];
+        TAIL_SLOT_FENCE(SET);
+    }
+    tail_sync<WAVE>();
+    double *cur = xt, *oth = m.T;
+    for (int k = 0; k < a.post; ++k) {
+        tail_jacobi<WAVE>(s, bt, cur, a.om[k % a.nom], oth, tid);
+        double *tmp = cur; cur = oth; oth = tmp;
+    }
+}
+#pragma clang fp contract(off)
+// One V-cycle on the right-hand side in B[0 .. n0); A / Bs hold levels 0 / 1 (tail_load_table), the cache the others.
+// Returns where the result of level 0 is.  Every thread of the workgroup calls it; the last barrier is behind it.
+template <typename SETA, typename MARK>
+__device__ __forceinline__ const double *tail_cycle(const TailDev &a, const TailLds &m, const SETA &A, const TailSet<1> &Bs,
+                                                    int tid, MARK &mark) {
+    const int nt = a.n;
+    const bool wave0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;      // (uniform: what wave 0 sets up alone stays in scalar registers)
+    TailSet<1> C;
+    int ts = nt;                 // levels ts .. nt-1 have at most 64 cells: wave 0 cycles them without workgroup barriers
+    for (int t = nt - 1; t >= 0 && a.L[t].ni * a.L[t].nj <= 64; --t) ts = t;
+    // ---- down, workgroup-wide levels
+    const int nfull = ts < nt - 1 ? ts : nt - 1;       // levels 0 .. nfull-1 are smoothed by the whole workgroup on the way down
+    for (int t = 0; t < nfull; ++t) {
+        if (t == 0) {
+            tail_down<false>(a, m, t, A, tid);
+        } else if (t == 1) {
+            tail_restrict<false>(a, m, t, Bs, tid);
+            tail_down<false>(a, m, t, Bs, tid);
+        } else {
+            tail_load_cache(a, m, t, C, tid);
+            tail_restrict<false>(a, m, t, C, tid);
+            tail_down<false>(a, m, t, C, tid);
+        }
+        mark();
+    }
+    int next_up;
+    if (ts < nt) {
+        if (wave0) {
+            for (int t = ts; t < nt - 1; ++t) {
+                if (t == 0) {
+                    tail_down<true>(a, m, t, A, tid);
+                } else if (t == 1) {
+                    tail_restrict<true>(a, m, t, Bs, tid);
+                    tail_down<true>(a, m, t, Bs, tid);
+                } else {
+                    tail_load_cache(a, m, t, C, tid);
+                    tail_restrict<true>(a, m, t, C, tid);
+                    tail_down<true>(a, m, t, C, tid);
                 }
             }
-            bc[idc] = s;
+            {
+                const int t = nt - 1;
+                if (t == 0) {
+                    tail_coarsest<true>(a, m, t, A, tid);
+                } else if (t == 1) {
+                    tail_restrict<true>(a, m, t, Bs, tid);
+                    tail_coarsest<true>(a, m, t, Bs, tid);
+                } else {
+                    tail_load_cache(a, m, t, C, tid);
+                    tail_restrict<true>(a, m, t, C, tid);
+                    tail_coarsest<true>(a, m, t, C, tid);
+                }
+            }
+            mark();
+            for (int t = nt - 2; t >= ts; --t) {
+                if (t == 0) {
+                    tail_up<true>(a, m, t, A, tid);
+                } else if (t == 1) {
+                    tail_up<true>(a, m, t, Bs, tid);
+                } else {
+                    tail_load_cache(a, m, t, C, tid);
+                    tail_up<true>(a, m, t, C, tid);
+                }
+            }
+            mark();
         }
         __syncthreads();
-    }
-    // ---- coarsest level: many damped sweeps from zero
-    const double *e;
-    {
+        next_up = ts - 1;
+    } else {
+        // (a coarsest level of more than 64 cells)
         const int t = nt - 1;
-        load_level(t);
-        double *xt = X + a.L[t].off, *bt = B + a.L[t].off;
-        double *cur = xt, *oth = T;
-        first(bt, a.om_coarse, cur, true);
-        const int sweeps = nt == 1 ? a.coarse_sweeps : a.coarse_sweeps;
-        for (int s = 1; s < sweeps; ++s) {
-            jacobi(bt, cur, a.om_coarse, oth, true);
-            double *tmp = cur; cur = oth; oth = tmp;
+        if (t == 0) {
+            tail_coarsest<false>(a, m, t, A, tid);
+        } else if (t == 1) {
+            tail_restrict<false>(a, m, t, Bs, tid);
+            tail_coarsest<false>(a, m, t, Bs, tid);
+        } else {
+            tail_load_cache(a, m, t, C, tid);
+            tail_restrict<false>(a, m, t, C, tid);
+            tail_coarsest<false>(a, m, t, C, tid);
         }
-        e = cur;
+        next_up = nt - 2;
+        mark();
     }
-    // ---- up: prolongation, post-smoothing
-    for (int t = nt - 2; t >= 0; --t) {
-        const int nic = a.L[t + 1].g.ni, fi = a.L[t].fi, fj = a.L[t].fj;
-        load_level(t);
-        double *xt = X + a.L[t].off, *bt = B + a.L[t].off;
+    // ---- up, workgroup-wide levels
+    for (int t = next_up; t >= 0; --t) {
+        if (t == 0) {
+            tail_up<false>(a, m, t, A, tid);
+        } else if (t == 1) {
+            tail_up<false>(a, m, t, Bs, tid);
+        } else {
+            tail_load_cache(a, m, t, C, tid);
+            tail_up<false>(a, m, t, C, tid);
+        }
+        mark();
+    }
+    return tail_result(a, m, 0);
+}
+
+__global__ __launch_bounds__(TAIL_NT) void k_mg_tail(TailDev a, const double *b0, double *x0) {
+    extern __shared__ double lds[];              // 2 * total + cells of the largest level + the coefficient cache, sized by the launch
+    const TailLds m = tail_lds(a, lds);
+    const int tid = threadIdx.x;
+    TailMark mark;
+    mark();
+    TailSet<TAIL_CPT> A;
+    TailSet<1> Bs{};
+    const int n0 = a.L[0].ni * a.L[0].nj;
+    // everything the cycle reads from global memory, in flight at once: couplings of every level (plain table loads
+    // first, they need no address arithmetic), then the right-hand side
+    tail_load_table(a, 0, A, tid);
+    if (a.n > 1) tail_load_table(a, 1, Bs, tid);
+    double bv[TAIL_CPT];
 #pragma unroll
-        for (int q = 0; q < TAIL_CPT; ++q) {
-            const int idx = tid + q * TAIL_NT;
-            if (idx < n) xt[idx] += a.gamma * e[((idx / ni) / fj) * nic + (idx % ni) / fi];
-        }
-        __syncthreads();
-        double *cur = xt, *oth = T;
-        for (int s = 0; s < a.post; ++s) {
-            jacobi(bt, cur, a.om[s % a.nom], oth, false);
-            double *tmp = cur; cur = oth; oth = tmp;
-        }
-        e = cur;
+    for (int q = 0; q < TAIL_CPT; ++q) {
+        const int idx = tid + q * TAIL_NT, ic = idx < n0 ? idx : 0;
+        bv[q] = b0[a.g0.cell(ic % a.L[0].ni, ic / a.L[0].ni)];
     }
+    tail_fill_cache(a, m, tid);
+#pragma unroll
+    for (int q = 0; q < TAIL_CPT; ++q) {
+        const int idx = tid + q * TAIL_NT;
+        if (idx < n0) m.B[idx] = bv[q];
+    }
+    __syncthreads();
+    mark();
+    const double *e = tail_cycle(a, m, A, Bs, tid, mark);
     // ---- result of the first tail level back to its plane
-    {
-        const TailLevel &L = a.L[0];
-        const int n0 = L.g.ni * L.g.nj;
-        for (int idx = tid; idx < n0; idx += TAIL_NT) x0[L.g.cell(idx % L.g.ni, idx / L.g.ni)] = e[idx];
+    for (int idx = tid; idx < n0; idx += TAIL_NT) x0[a.g0.cell(idx % a.L[0].ni, idx / a.L[0].ni)] = e[idx];
+    mark();
+#ifdef TAIL_CLOCKS
+    if (tid == 0) g_tail_clk[255] = mark.n;
+#endif
+}
+#ifdef TAIL_CLOCKS
+extern "C" int cfd_debug_tail_clocks(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_clk), sizeof(g_tail_clk));
+}
+#endif
+
+// ------------------------------------------------------------------ a whole MG-PCG solve in one workgroup
+// Meshes whose pressure hierarchy fits the LDS of one workgroup together with the Krylov vectors (the reference's own
+// cases are 5 x 20 ... 15 x 40 cells; up to about 50 x 50): the solve that pcg_mg() issues as seven launches per iteration --
+// the V-cycle tail, three dot products with their finishing kernels, the direction and the residual update -- is ONE launch:
+// r lives in the right-hand side slots of tail level 0, p and the diagonal of level 0 in two more LDS planes, x and q = A p
+// in registers, the dot products are workgroup sums, and the stopping test |r| <= tol |b| is evaluated on the device after
+// every iteration, so the solve takes exactly the iterations the host-checked loop would take without the host looking.
+// out[0] = iterations, out[1] = |r|^2, out[2] = |b|^2 (out[8] on the slot layout of the speculative path).
+// Same algorithm as pcg_mg (k_cg_p / k_cg_q / k_cg_xr expressions, V-cycle of k_mg_tail); x = 0 initially; the nullspace
+// shift of the pinned cell is applied before the store.
+struct PcgTailArgs {
+    double tol, pin_value;
+    int maxiter, ns_active, pin_idx;      // pin_idx: slot of the reference cell on level 0 (-1: none)
+    int bb_slot;                          // where |b|^2 goes in out[]
+};
+__device__ __forceinline__ double tail_block_sum(double v, double *red, int &buf, int tid) {
+    const double w = wsum(v);
+    double *r = red + 16 * buf;
+    if ((tid & 63) == 0) r[tid >> 6] = w;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < TAIL_NT / 64; ++k) tot += r[k];
+    buf ^= 1;        // the next sum writes the other half: no barrier between these reads and those writes
+    return tot;
+}
+// CPT: cells per thread on level 0 (1 for meshes of at most TAIL_NT cells: the one-slot set leaves the registers to the cycle)
+template <int CPT>
+__global__ __launch_bounds__(TAIL_NT) void k_pcg_tail(TailDev a, PcgTailArgs pa, const double *b0, double *x0, double *out) {
+    extern __shared__ double lds[];      // the tail's planes, then p, the diagonal of level 0, x and the reduction slots
+    const TailLds m = tail_lds(a, lds);
+    const int tid = threadIdx.x;
+    const int n0 = a.L[0].ni * a.L[0].nj;
+    double *Pv = m.CF + 7 * (size_t)m.ncache, *DG = Pv + n0, *XS = DG + n0, *red = XS + n0;
+    TailMark mark;
+    TailSet<CPT> A;
+    TailSet<1> Bs{};
+    double bv[CPT], qv[CPT];
+    tail_load_table(a, 0, A, tid);
+    if (a.n > 1) tail_load_table(a, 1, Bs, tid);
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int idx = tid + q * TAIL_NT, ic = idx < n0 ? idx : 0;
+        bv[q] = b0[a.g0.cell(ic % a.L[0].ni, ic / a.L[0].ni)];
+    }
+    tail_fill_cache(a, m, tid);
+    double bsq = 0.0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int idx = tid + q * TAIL_NT;
+        if (idx < n0) {
+            m.B[idx] = bv[q];
+            XS[idx] = 0.0;
+            DG[idx] = tail_ld<double>(a.tab + 4 * a.total, (unsigned)idx * 8u);
+            bsq += bv[q] * bv[q];
+        }
+    }
+    int buf = 0;
+    const double bb = tail_block_sum(bsq, red, buf, tid);      // (its barrier also publishes B, DG and the cache)
+    double rr = bb, rz_old = 0.0;
+    int it = 0;
+    if (bb == bb && bb != 0.0) {
+        while (it < pa.maxiter) {
+            const double *z = tail_cycle(a, m, A, Bs, tid, mark);
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int idx = tid + q * TAIL_NT;
+                if (idx < n0) acc += m.B[idx] * z[idx];
+            }
+            const double rz = tail_block_sum(acc, red, buf, tid);
+            const double beta = it == 0 ? 0.0 : safe_div(rz, rz_old);
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int idx = tid + q * TAIL_NT;
+                if (idx < n0) Pv[idx] = it == 0 ? z[idx] : z[idx] + beta * Pv[idx];
+            }
+            __syncthreads();
+            acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int idx = tid + q * TAIL_NT;
+                qv[q] = 0.0;
+                if (idx < n0) {
+                    qv[q] = DG[idx] * Pv[idx] - tail_nbr(A, q, idx, Pv);
+                    acc += qv[q] * Pv[idx];
+                }
+            }
+            const double pq = tail_block_sum(acc, red, buf, tid);
+            const double alpha = safe_div(rz, pq);
+            acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int idx = tid + q * TAIL_NT;
+                if (idx < n0) {
+                    XS[idx] = XS[idx] + alpha * Pv[idx];
+                    const double rn = m.B[idx] - alpha * qv[q];
+                    m.B[idx] = rn;
+                    acc += rn * rn;
+                }
+            }
+            rr = tail_block_sum(acc, red, buf, tid);            // (its barrier publishes r to the next V-cycle)
+            rz_old = rz;
+            ++it;
+            if (!(rr == rr) || sqrt(rr) <= pa.tol * sqrt(bb)) break;
+        }
+    }
+    // nullspace form: the constant that moves the solution to the reference value at the reference cell
+    double shift = 0.0;
+    if (pa.ns_active) {
+        double *sh = red + 32;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q)
+            if (tid + q * TAIL_NT == pa.pin_idx) sh[0] = pa.pin_value - XS[pa.pin_idx];
+        __syncthreads();
+        if (pa.pin_idx >= 0) shift = sh[0];
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int idx = tid + q * TAIL_NT;
+        if (idx < n0) x0[a.g0.cell(idx % a.L[0].ni, idx / a.L[0].ni)] = XS[idx] + shift;
+    }
+    if (tid == 0) {
+        out[0] = (double)it;
+        out[1] = rr;
+        out[pa.bb_slot] = bb;
     }
 }
 
@@ -2794,15 +3198,24 @@ int build_pressure_hierarchy(Ctx *c) {
             // one-sweep-per-launch form around the tail.  tail_from = 1 keeps the finest level out.
             const int lt0 = (c->tail_from == 0 && !level_fusable(c, 0, c->levels[0].g, coarse_view(c, 1))) ? 0 : 1;
             for (int lt = std::max(lt0, std::max(la, last_line + 1)); lt < nl; ++lt) {
-                long total = 0;
-                for (int l = lt; l < nl; ++l) total += (long)c->levels[l].g.ni * c->levels[l].g.nj;
+                // the first tail level has up to TAIL_CPT cells per thread, the second one, the others share one cached cell per thread
+                long total = 0, ncache = 0, second = 0;
+                for (int l = lt; l < nl; ++l) {
+                    const long cells = (long)c->levels[l].g.ni * c->levels[l].g.nj;
+                    total += cells;
+                    if (l == lt + 1) second = cells;
+                    if (l >= lt + 2) ncache += cells;
+                }
                 const long top = (long)c->levels[lt].g.ni * c->levels[lt].g.nj;
-                if (top > TAIL_MAX_CELLS || nl - lt > TAIL_MAX_LEVELS || 2 * total + top > TAIL_LDS_DOUBLES) continue;
+                if (top > TAIL_MAX_CELLS || second > TAIL_NT || ncache > TAIL_NT || nl - lt > TAIL_MAX_LEVELS ||
+                    tail_lds_doubles(total, top, ncache) > TAIL_LDS_DOUBLES)
+                    continue;
                 TailArgs &a = c->tail;
                 a = TailArgs{};
                 a.n = nl - lt;
                 a.total = (int)total;
-                int off = 0;
+                a.ncache = (int)ncache;
+                int off = 0, coff = 0;
                 for (int l = lt; l < nl; ++l) {
                     const Level &L = c->levels[l];
                     TailLevel &t = a.L[l - lt];
@@ -2810,10 +3223,57 @@ int build_pressure_hierarchy(Ctx *c) {
                     t.fi = t.fj = 1;
                     if (l + 1 < nl) factors(L.g, c->levels[l + 1].g, t.fi, t.fj);
                     off += L.g.ni * L.g.nj;
+                    t.coff = coff;
+                    if (l >= lt + 2) coff += L.g.ni * L.g.nj;
                 }
+                a.per_i = c->pp_per_i; a.per_j = c->pp_per_j;
+                if ((size_t)a.total * 64 > TAIL_TABLE_BYTES) { set_error("internal: V-cycle tail table exceeds its share of the workspace"); return CFD_E_STATE; }
+                a.tab = c->tail_tab;
+                hipLaunchKernelGGL(k_tail_pack, dim3((a.total + 255) / 256), dim3(256), 0, st, a, c->tail_tab);
+                CFD_HIP(hipGetLastError());
                 c->tail_lt = lt;
                 break;
             }
+        }
+    }
+    // ---- the whole solve in one workgroup (k_pcg_tail): the hierarchy from level 0 with the Krylov planes beside it
+    c->ptail_ok = false;
+    {
+        const int nl = (int)c->levels.size();
+        bool plain = c->pcg_tail && c->comm.nranks == 1 && !c->semi_on && nl <= TAIL_MAX_LEVELS;
+        for (int l = 0; l < nl; ++l) plain = plain && !c->levels[l].line;
+        long total = 0, ncache = 0, second = 0;
+        for (int l = 0; l < nl; ++l) {
+            const long cells = (long)c->levels[l].g.ni * c->levels[l].g.nj;
+            total += cells;
+            if (l == 1) second = cells;
+            if (l >= 2) ncache += cells;
+        }
+        const long top = (long)c->levels[0].g.ni * c->levels[0].g.nj;
+        if (plain && top <= c->pcg_tail_cells && top <= TAIL_MAX_CELLS && second <= TAIL_NT && ncache <= TAIL_NT &&
+            pcg_tail_lds_doubles(total, top, ncache) <= TAIL_LDS_DOUBLES && (size_t)total * 64 <= TAIL_TABLE_BYTES) {
+            TailArgs &a = c->ptail;
+            a = TailArgs{};
+            a.n = nl;
+            a.total = (int)total;
+            a.ncache = (int)ncache;
+            int off = 0, coff = 0;
+            for (int l = 0; l < nl; ++l) {
+                const Level &L = c->levels[l];
+                TailLevel &t = a.L[l];
+                t.ci = L.ci; t.cj = L.cj; t.D = L.D; t.g = L.g; t.off = off;
+                t.fi = t.fj = 1;
+                if (l + 1 < nl) factors(L.g, c->levels[l + 1].g, t.fi, t.fj);
+                off += L.g.ni * L.g.nj;
+                t.coff = coff;
+                if (l >= 2) coff += L.g.ni * L.g.nj;
+            }
+            a.per_i = c->pp_per_i; a.per_j = c->pp_per_j;
+            double *tab = c->tail_tab + TAIL_TABLE_BYTES / sizeof(double);       // (second half: the V-cycle tail has the first)
+            a.tab = tab;
+            hipLaunchKernelGGL(k_tail_pack, dim3((a.total + 255) / 256), dim3(256), 0, st, a, tab);
+            CFD_HIP(hipGetLastError());
+            c->ptail_ok = true;
         }
     }
     // ---- single-precision face planes of the levels the fused marching kernels cycle.  The V-cycle built on them is
@@ -2914,6 +3374,24 @@ static inline MarchGeo march_geo_w(const Geo &g, int W) {
 
 // One V-cycle: z ~= A^-1 r starting from zero.  The result lands in *zout, which is
 // either z0 or z1 (Jacobi ping-pong).
+// a tail as built with the hierarchy + what cfd_set_multigrid may have changed since
+static TailDev tail_launch_args(const Ctx *c, const TailArgs &built) {
+    TailDev a{};
+    a.n = built.n; a.total = built.total; a.ncache = built.ncache; a.tab = built.tab;
+    a.g0 = built.L[0].g;
+    for (int t = 0; t < built.n; ++t) a.L[t] = TailDevLevel{built.L[t].g.ni, built.L[t].g.nj, built.L[t].off, built.L[t].coff};
+    a.per_i = c->pp_per_i; a.per_j = c->pp_per_j;
+    a.pre = c->mg_pre < 1 ? 1 : c->mg_pre; a.post = c->mg_post; a.coarse_sweeps = c->mg_coarse_sweeps < 1 ? 1 : c->mg_coarse_sweeps;
+    a.nom = c->mg_nom < 4 ? c->mg_nom : 4;
+    for (int q = 0; q < a.nom; ++q) a.om[q] = c->om_at(q);
+    a.om_coarse = c->om_mean(); a.gamma = c->mg_gamma;
+    return a;
+}
+static int raise_tail_lds_limit(const void *kernel) {
+    CFD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_DOUBLES * (int)sizeof(double)));
+    return CFD_OK;
+}
+
 static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks,
                        const ResidFuse *rf = nullptr, bool *z_f32 = nullptr) {
     if (z_f32) *z_f32 = false;
@@ -3042,16 +3520,11 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (to_agg) CFD_TRY(all_gather_rows(c, cb + NG * (size_t)cg.pitch, C.b + NG * (size_t)cg.pitch, (size_t)cg.nj * cg.pitch));
     }
     if (lt >= 0) {
-        TailArgs a = c->tail;
-        a.per_i = c->pp_per_i; a.per_j = c->pp_per_j; a.pre = pre; a.post = post; a.coarse_sweeps = c->mg_coarse_sweeps;
-        a.nom = c->mg_nom < 4 ? c->mg_nom : 4;
-        for (int q = 0; q < a.nom; ++q) a.om[q] = c->om_at(q);
-        a.om_coarse = c->om_mean(); a.gamma = c->mg_gamma;
-        const size_t lds_bytes = (2 * (size_t)a.total + (size_t)a.L[0].g.ni * a.L[0].g.nj) * sizeof(double);
+        const TailDev a = tail_launch_args(c, c->tail);
+        const size_t lds_bytes = (size_t)tail_lds_doubles(a.total, (long)a.L[0].ni * a.L[0].nj, a.ncache) * sizeof(double);
         static bool lds_limit_raised = false;
         if (!lds_limit_raised) {
-            CFD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mg_tail), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        TAIL_LDS_DOUBLES * (int)sizeof(double)));
+            CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_mg_tail)));
             lds_limit_raised = true;
         }
         hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(TAIL_NT), lds_bytes, st, a, rhs[lt], cur[lt]);
@@ -3388,7 +3861,53 @@ static int ns_shift_scalar(Ctx *c, const CgScal *S, int gen, int with_p, int xze
     return all_reduce(c, c->scal + 81, 1, 0);
 }
 
+// The whole solve as one launch of k_pcg_tail (meshes whose hierarchy fits one workgroup's LDS, Ctx::ptail_ok).  The host
+// reads three scalars afterwards -- or, in a speculative iteration, leaves them to the iteration's closing read: the
+// device has already applied the stopping test, so there is no schedule to replay and nothing to repeat unless the
+// solve ran into maxiter.
+static int pcg_tail_solve(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres) {
+    const TailDev a = tail_launch_args(c, c->ptail);
+    const Geo &g = a.g0;
+    const long top = (long)g.ni * g.nj;
+    const bool spec = c->spec_on && c->spec_pcg.n < 4;
+    PcgTailArgs pa{};
+    pa.tol = tol; pa.pin_value = c->pin_value; pa.maxiter = maxiter; pa.ns_active = c->p_ns_active ? 1 : 0;
+    pa.pin_idx = c->pin_i >= 0 ? c->pin_j * g.ni + c->pin_i : -1;
+    pa.bb_slot = spec ? 8 : 2;
+    double *out = spec ? c->scal + SPEC_PCG_OFF + SPEC_PCG_STRIDE * c->spec_pcg.n : c->scal + CG_OFF;
+    static bool lds_limit_raised = false;
+    if (!lds_limit_raised) {
+        CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_pcg_tail<1>)));
+        CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_pcg_tail<TAIL_CPT>)));
+        lds_limit_raised = true;
+    }
+    const size_t lds_bytes = (size_t)pcg_tail_lds_doubles(a.total, top, a.ncache) * sizeof(double);
+    if (top <= TAIL_NT) hipLaunchKernelGGL(k_pcg_tail<1>, dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a, pa, b, x, out);
+    else hipLaunchKernelGGL(k_pcg_tail<TAIL_CPT>, dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a, pa, b, x, out);
+    CFD_HIP(hipGetLastError());
+    c->kc[KC_PCG_TAIL] += 1;
+    c->bb_ready = false;
+    if (spec) {
+        Ctx::SpecPcg &sp = c->spec_pcg;
+        sp.hint[sp.n] = -1;              // stopped by the device: slot[0] = iterations, slot[1] = |r|^2, slot[8] = |b|^2
+        sp.tol[sp.n] = tol;
+        sp.n += 1;
+        *iters = c->p_iters_hint;
+        *relres = 0.0;                   // known when the iteration's closing read has arrived (spec_verify)
+        return CFD_OK;
+    }
+    double h[3];
+    CFD_TRY(read_scalars(c, CG_OFF, 3, h));
+    if (!(h[2] == h[2])) { set_error("pressure solve: non-finite right-hand side"); return CFD_E_NUMERIC; }
+    if (!(h[1] == h[1])) { set_error("PCG: non-finite residual at iteration %d", (int)h[0]); return CFD_E_NUMERIC; }
+    *iters = (int)h[0];
+    *relres = h[2] > 0.0 ? sqrt(h[1] / h[2]) : 0.0;
+    c->p_iters_hint = *iters;
+    return CFD_OK;
+}
+
 static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, int *iters, double *relres) {
+    if (c->ptail_ok && c->pcg_tail) return pcg_tail_solve(c, b, x, tol, maxiter, iters, relres);
     const Level &L0 = c->levels[0];
     const OpDev op = level_op(c, L0);
     const Geo g = op.g;
@@ -3652,6 +4171,15 @@ int spec_verify(Ctx *c, double *res, bool *ok) {
     const Ctx::SpecPcg &sp = c->spec_pcg;
     for (int s = 0; s < sp.n; ++s) {
         const double *slot = h + SPEC_PCG_OFF + SPEC_PCG_STRIDE * s;
+        if (sp.hint[s] < 0) {
+            // k_pcg_tail: the device applied the stopping test; not met means the solve ran into maxiter
+            const double bb = slot[8], rr = slot[1];
+            if (!(bb == bb) || !(rr == rr) || !(sqrt(rr) <= sp.tol[s] * sqrt(bb))) { *ok = false; continue; }
+            c->stats.p_relres = bb > 0.0 ? sqrt(rr / bb) : 0.0;
+            c->stats.p_iters = (int)slot[0];
+            c->p_iters_hint = (int)slot[0];
+            continue;
+        }
         const double bb = slot[8], rr = slot[sp.hint[s] & 7];
         if (!(bb == bb) || !(rr == rr) || !(sqrt(rr) <= sp.tol[s] * sqrt(bb))) { *ok = false; continue; }
         c->stats.p_relres = bb > 0.0 ? sqrt(rr / bb) : 0.0;

@@ -448,8 +448,9 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
  * [12] max number of line-smoothed levels, [13] levels cycled by the single-launch V-cycle tail, [14] launches of the fused
  * correction / flux kernel, [15] levels of the semi-coarsened line multigrid, [16] inner iterations that ran speculatively
  * (option "speculate": solves replay the previous iteration's schedule, one host read at the iteration's end, stopping
- * tests evaluated then), [17] of those, iterations whose test failed and that were repeated host-checked.
- * n <= 18 entries are written.  No counterpart in the reference.  */
+ * tests evaluated then), [17] of those, iterations whose test failed and that were repeated host-checked, [18] pressure
+ * solves that were ONE launch (k_pcg_tail: the whole MG-PCG solve of a mesh whose hierarchy fits one workgroup's LDS).
+ * n <= 19 entries are written.  No counterpart in the reference.  */
 int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset);
 /* Host-side cost of the calls so far, process wide: out[0] = kernel launches, out[1] = blocking stream
  * synchronisations the library issued (each one idles the GPU while the host reads a scalar).  They bound the step
