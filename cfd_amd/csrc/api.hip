@@ -653,6 +653,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "fuse_resid") c->fuse_resid = iv ? 1 : 0;
     else if (n == "nt_stores") c->nt_stores = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
+    else if (n == "march_ls_model") c->march_ls_model = iv ? 1 : 0;
     else if (n == "scalar_nu") { c->scalar_nu = iv ? 1 : 0; c->ap_cached = false; }
     else if (n == "host_lag") c->host_lag = iv ? 1 : 0;
     else if (n == "plane_swap") c->plane_swap = iv ? 1 : 0;

@@ -420,6 +420,7 @@ struct Ctx {
     int cheb_prefetch = 2;       // rows of loads a k_chebk wave keeps in flight (1 or 2)
     int nt_stores = -1;          // nontemporal stores in the streaming kernels: -1 = when a plane exceeds the Infinity Cache
     int march_ls = 0;            // rows per segment of the K >= 3 marching kernels (0 = default)
+    int march_ls_model = 1;      // 1: multigrid levels of few wave rounds take the segment length of march_geo_k's cost model
     long long kc[KC_COUNT] = {};  // launches per kernel family (cfd_kernel_counts)
     inline int nts(const Geo &geo) const {
         return nt_stores >= 0 ? nt_stores : (geo.plane_elems() * sizeof(double) > ((size_t)256 << 20) ? 1 : 0);
@@ -498,7 +499,7 @@ struct Ctx {
     TailArgs ptail{};            // the hierarchy from level 0 for k_pcg_tail (the whole MG-PCG solve in one launch)
     bool ptail_ok = false;
     int pcg_tail = 1;            // 1: meshes of at most pcg_tail_cells cells whose hierarchy fits one workgroup's LDS solve p' in one launch
-    int pcg_tail_cells = 1024;
+    int pcg_tail_cells = TAIL_MAX_CELLS;   // (what fits is decided by the LDS: about 2800 cells)
     int tail_lt = -1;            // first level of the tail (-1: none), set when the hierarchy is built
     TailArgs tail{};
     double *sst_S = nullptr, *sst_F1 = nullptr, *sst_F2 = nullptr, *sst_Dk = nullptr, *sst_Dw = nullptr, *sst_dw = nullptr;

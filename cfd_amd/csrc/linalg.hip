@@ -2105,7 +2105,8 @@ static inline bool level_fusable(const Ctx *c, int lvl, const Geo &F, const Geo 
     if (c->levels[lvl].line || c->semi_on) return false;       // line-smoothed levels run their own kernels
     return c->mg_fused && k_ok && F.ni >= 16 && F.nj >= 16 && C.ni == (F.ni + 1) / 2 && C.nj == (F.nj + 1) / 2;
 }
-static inline MarchGeo march_geo_k(const Geo &g, int K);
+static inline MarchGeo march_geo_k(const Geo &g, int K, bool march_ls_model);
+constexpr long MARCH_WAVE_SLOTS = 4096;      // 256 CUs x 4 SIMDs x 4 waves (amdgpu_waves_per_eu(4, 4) of the three-sweep kernels)
 static inline int march_blocks(const MarchGeo &m) {
     const long items = (long)m.nstrips * m.nsegs;
     long nb = (items + 3) / 4;
@@ -2124,16 +2125,33 @@ static inline int march_grid(const MarchGeo &m, int wide, bool lock4 = false) {
     return (int)(items < MAX_PARTIALS ? items : MAX_PARTIALS);
 }
 // K halo lanes / rows per side: narrower strips, longer segments to amortise the 2K extra rows
-static inline MarchGeo march_geo_k(const Geo &g, int K) {
+static inline MarchGeo march_geo_k(const Geo &g, int K, bool march_ls_model) {
     if (K <= 2) return march_geo(g);
     MarchGeo m;
     m.nstrips = (g.ni + (64 - 2 * K) - 1) / (64 - 2 * K);
     int Ls = 64;
-    while (Ls > 8 && (long)m.nstrips * ((g.nj + Ls - 1) / Ls) < 8192) Ls /= 2;
+    auto items_at = [&](int len) { return (long)m.nstrips * ((g.nj + len - 1) / len); };
+    if (march_ls_model && items_at(64) < 3 * MARCH_WAVE_SLOTS) {
+        // A level that fills the GPU's wave slots (four waves per SIMD) less than three times over: its launch lasts
+        // rounds x (rows per item) row trips, a round being one item per slot -- 2.2 rounds cost three, and halving the
+        // segments to get more items buys 2K redundant rows per item (4096^2 at Ls = 32: 9088 items of 38 rows, three
+        // rounds; 2048^2 at Ls = 8: 14 rows per item for 8 of output).  Take the segment length that minimises
+        // rounds x (Ls + 2K + start-up); levels below one round end at the shortest chain of dependent row trips.
+        double best = 1.0e30;
+        for (int len = 2; len <= 64; len += 2) {       // (even: a segment holds whole 2 x 2 aggregates)
+            const long rounds = (items_at(len) + MARCH_WAVE_SLOTS - 1) / MARCH_WAVE_SLOTS;
+            const double cost = (double)rounds * (len + 2 * K + 3);
+            if (cost < best) { best = cost; Ls = len; }
+        }
+        m.Ls = Ls;
+        m.nsegs = (g.nj + Ls - 1) / Ls;
+        return m;
+    }
+    while (Ls > 8 && items_at(Ls) < 8192) Ls /= 2;
     // levels too small to fill the GPU even then are chains of dependent row trips (Ls + 2K of them per launch):
     // shorter segments shorten the chain, the redundant halo rows cost nothing there
     // (8192^2: 43.35 -> 43.15 ms per step from the 1024^2 ... 128^2 levels; 1024^2: see DESIGN section 5)
-    while (Ls > 2 && (long)m.nstrips * ((g.nj + Ls - 1) / Ls) < 2048) Ls /= 2;
+    while (Ls > 2 && items_at(Ls) < 2048) Ls /= 2;
     m.Ls = Ls;
     m.nsegs = (g.nj + Ls - 1) / Ls;
     return m;
@@ -3438,7 +3456,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         const Geo cg = coarse_view(c, l + 1);
         double *cb = to_agg ? C.s0 : C.b;
         if (level_fusable(c, l, L.g, cg)) {
-            MarchGeo mgeo = march_geo_k(L.g, KS);
+            MarchGeo mgeo = march_geo_k(L.g, KS, c->march_ls_model != 0);
             mgeo.xcd = KS == 3 ? c->xcd_map : 0;
             const int wide = KS == 3 ? march_wide(c, mgeo, l > 0 ? WIDE_MG_COARSE : (rf ? WIDE_MG_DOWN_RF : WIDE_MG_DOWN)) : 4;
             const dim3 grid(march_grid(mgeo, wide));
@@ -3562,7 +3580,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
         else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, level_fusable(c, l, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
         if (level_fusable(c, l, L.g, cg)) {
-            MarchGeo mgeo = march_geo_k(L.g, KS);
+            MarchGeo mgeo = march_geo_k(L.g, KS, c->march_ls_model != 0);
             mgeo.xcd = KS == 3 ? c->xcd_map : 0;
             const int wide = KS == 3 ? march_wide(c, mgeo, l > 0 ? WIDE_MG_COARSE : WIDE_MG_UP) : 4;
             const dim3 grid(march_grid(mgeo, wide));

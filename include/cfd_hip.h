@@ -436,6 +436,8 @@ int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, doub
  * face coefficients rounded to single precision -- the Krylov operator stays double, the solution is unchanged),
  * "mg_semi" (1 / 0: stretched meshes are cycled by zebra whole-line relaxation along i with semi-coarsening along j /
  * by the alternating block line smoother with full coarsening; one rank, frozen operator, lines of at most 8192 cells),
+ * "pcg_tail" (1 / 0: the pressure solve of a mesh whose hierarchy fits one workgroup's LDS is one launch with the
+ * stopping test on the device / the launch-per-phase loop), "pcg_tail_cells" (cell limit of that path), "march_ls_model",
  * "speculate" (-1 / 0 / 1: inner iterations with one host read at their end, see cfd_kernel_counts; auto = contexts of
  * at most 4M cells), "fuse_correct_slab", "skip_fresh_bc", "probe_capacity" (launches a probe run can time), "mg_v32_emul" (measurement aid), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
  * next pre-smoothing pass / by its own pass).  INTEGRATION.md section 4 has the table.  No counterpart in the reference.     */

@@ -721,6 +721,8 @@ PCG_TAIL_CASES = {
     "komega_32x32": (lambda: cases.channel_forced(n=32, steps=3, turbulent=True), cases.perturbed_parabola),
     "inlet_outlet_20x10": (lambda: cases.inlet_outlet_channel(20, 10, steps=4), None),    # Dirichlet pressure: no nullspace
     "inlet_outlet_40x24": (lambda: cases.inlet_outlet_channel(40, 24, steps=3), None),
+    "periodic_48x40": (lambda: cases.lam_channel(48, 40, steps=3), None),                 # more than 1024 cells: four cells per thread
+    "inlet_outlet_50x52": (lambda: cases.inlet_outlet_channel(50, 52, steps=3), None),    # 2600 cells, close to what the LDS holds
     "couette_piso_8x10": (lambda: cases.couette_piso(8, 10, steps=4), cases.perturbed_rest),   # several solves per step
     "half_cylinder_12x16": (lambda: cases.half_cylinder(nr=12, nt=16, steps=3), None),    # curvilinear, symmetry rows
     "channel_komega_5x20": (lambda: cases.channel_komega_5x20(steps=6, tol=cases.TIGHT), cases.ramp_initial_u),  # the reference's own case
