@@ -670,6 +670,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "fused_min_pcg") c->fused_min_pcg = iv < 4 ? 4 : iv;
     else if (n == "fused_min_cf") c->fused_min_cf = iv < 4 ? 4 : iv;
     else if (n == "tail_from") c->tail_from = iv ? 1 : 0;
+    else if (n == "cheb_tail") c->cheb_tail = iv ? 1 : 0;
+    else if (n == "cheb_tail_cells") { if (iv < 0 || iv > TAIL_MAX_CELLS) { set_error("cheb_tail_cells: 0 .. %d", TAIL_MAX_CELLS); return CFD_E_ARG; } c->cheb_tail_cells = iv; }
     else if (n == "pcg_tail") { c->pcg_tail = iv ? 1 : 0; c->p_built = false; }
     else if (n == "pcg_tail_cells") { if (iv < 0 || iv > TAIL_MAX_CELLS) { set_error("pcg_tail_cells: 0 .. %d", TAIL_MAX_CELLS); return CFD_E_ARG; } c->pcg_tail_cells = iv; c->p_built = false; }
     else if (n == "speculate") c->speculate = iv < 0 ? -1 : (iv ? 1 : 0);
@@ -1033,6 +1035,7 @@ static int run_iteration(Ctx *c, double *res, const std::function<int()> &body) 
     const int cur0 = c->cur;
     c->spec_cheb = Ctx::SpecCheb{};
     c->spec_pcg = Ctx::SpecPcg{};
+    c->spec_chebt = Ctx::SpecChebT{};
     c->spec_on = spec;
     int rc = body();
     c->spec_on = false;
@@ -1041,7 +1044,7 @@ static int run_iteration(Ctx *c, double *res, const std::function<int()> &body) 
         return rc;
     }
     bool ok = rc == CFD_OK;
-    const bool any = c->spec_cheb.used || c->spec_pcg.n > 0;
+    const bool any = c->spec_cheb.used || c->spec_pcg.n > 0 || c->spec_chebt.n > 0;
     if (ok) CFD_TRY(spec_verify(c, res, &ok));
     if (ok) {
         if (any) { ++c->spec_age; c->kc[KC_SPEC_ITERS] += 1; }
@@ -1053,6 +1056,7 @@ static int run_iteration(Ctx *c, double *res, const std::function<int()> &body) 
     c->rhs_ahead = false; c->dt_ahead = false; c->dt_host_valid = false; c->bc_fresh = false;
     c->spec_cheb = Ctx::SpecCheb{};
     c->spec_pcg = Ctx::SpecPcg{};
+    c->spec_chebt = Ctx::SpecChebT{};
     c->spec_age = 0;
     return body();
 }

@@ -196,7 +196,7 @@ __device__ __forceinline__ void store_stream_f32(float *p, float v, int nt) {
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
-    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_SPEC_ITERS, KC_SPEC_REDONE, KC_PCG_TAIL, KC_COUNT = 19
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_SPEC_ITERS, KC_SPEC_REDONE, KC_PCG_TAIL, KC_CHEB_TAIL, KC_COUNT = 20
 };
 
 // ------------------------------------------------------------------ multigrid level
@@ -383,6 +383,14 @@ struct Ctx {
         int hint[4] = {0, 0, 0, 0};
         double tol[4] = {0, 0, 0, 0};
     } spec_pcg;
+    static constexpr int SPEC_CHEBT_MAX = 3;
+    struct SpecChebT {                 // one-launch Chebyshev solves (k_cheb_tail) of a speculative iteration
+        int n = 0;
+        int nb[SPEC_CHEBT_MAX] = {};
+        bool momentum[SPEC_CHEBT_MAX] = {};
+    } spec_chebt;
+    int cheb_tail = 1;                 // 1: transport solves of meshes of at most cheb_tail_cells cells are one launch (k_cheb_tail)
+    int cheb_tail_cells = 2800;        // (the size up to which the pressure solve is one launch as well)
     int cf_agreed = -1;                // slab ranks' common answer to correct_flux_ok (-1: not asked yet)
     bool bc_fresh = false;             // the ghosts of u, v, p [bc_cur] are those of k_flow_bc + exchange on the current values
     int bc_cur = -1, skip_fresh_bc = 1;

@@ -1199,6 +1199,210 @@ __global__ __launch_bounds__(TAIL_NT) void k_pcg_tail(TailDev a, PcgTailArgs pa,
     }
 }
 
+// ------------------------------------------------------------------ a whole Chebyshev transport solve in one workgroup
+// The momentum / k / omega solve of a mesh of at most CHEB_TAIL_MAX_CELLS cells as ONE launch: what chebyshev_jacobi()
+// issues as (row-sum bound + finish, first pass + finish, host read, kpred one-iteration passes, finish, host read) runs
+// in one 1024-thread workgroup with both iterates of every right-hand side in LDS and the operator rows in registers.
+// Same algorithm and the same expressions as the one-iteration form (k_rowsum_bound, k_cheb, the host's prediction of the
+// iteration count from the Chebyshev bound, the stopping test on the iterate the last pass started from): the iterates are
+// those of that form bit for bit; only the residual sums are taken in another order.
+// out[0] = status (1: solved; 0: not a system for this solver, x untouched -- the caller goes to BiCGStab; 2: bound not met
+// within the limit, x = best iterate -- BiCGStab continues from it; 3: non-finite right-hand side), out[1] = iterations,
+// out[2 + q] = |r|^2, out[4 + q] = |b|^2, out[6] = rho.
+struct ChebTailArgs {
+    const double *ci, *cj, *D;
+    Geo g;
+    int per_i, per_j;
+    const double *b[2], *x0[2];
+    double *x[2];
+    double tol, rho_max;
+    int maxiter, cheb_max_iters;
+    double *out;
+};
+template <int NQ>
+__device__ __forceinline__ void cheb_tail_sums(double (&v)[NQ], double *red, int &buf, int tid) {
+    double *r = red + NQ * 16 * buf;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const double w = wsum(v[q]);
+        if ((tid & 63) == 0) r[q * 16 + (tid >> 6)] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < TAIL_NT / 64; ++k) tot += r[q * 16 + k];
+        v[q] = tot;
+    }
+    buf ^= 1;
+}
+template <int NB, int CPT>
+__global__ __launch_bounds__(TAIL_NT) void k_cheb_tail(ChebTailArgs a) {
+    extern __shared__ double lds[];          // per right-hand side two iterate planes of n doubles, then the reduction slots
+    const int tid = threadIdx.x;
+    const Geo g = a.g;
+    const int ni = g.ni, nj = g.nj, n = ni * nj;
+    // plane w (0: A, 1: B) of right-hand side q (selectors, not pointer arrays: those would live in scratch memory)
+    auto plane = [&](int q, int w) { return lds + (size_t)(2 * q + w) * n; };
+    double *red = lds + (size_t)2 * NB * n;
+    // operator rows and right-hand sides of this thread's cells; couplings without a neighbour are zero (offdiag skips them)
+    double d[CPT], cw[CPT], ce[CPT], cs[CPT], cn[CPT], bq[CPT][NB];
+    int fl[CPT];
+    const int dwi = a.per_i ? ni : 1, dsj = a.per_j ? n : ni;
+    double rho_loc = 0.0;
+#pragma unroll
+    for (int s = 0; s < CPT; ++s) {
+        const int idx = tid + s * TAIL_NT, ic = idx < n ? idx : 0;
+        const int i = ic % ni, j = ic / ni;
+        const size_t c = g.cell(i, j), P = g.pitch;
+        fl[s] = (i == 0 ? 1 : 0) | (i == ni - 1 ? 2 : 0) | (j == 0 ? 4 : 0) | (j == nj - 1 ? 8 : 0);
+        const double w = a.ci[c], e = a.ci[c + 1], so = a.cj[c], no = a.cj[c + P];
+        d[s] = a.D[c];
+        cw[s] = (!(fl[s] & 1) || a.per_i) ? w : 0.0;
+        ce[s] = (!(fl[s] & 2) || a.per_i) ? e : 0.0;
+        cs[s] = (!(fl[s] & 4) || a.per_j) ? so : 0.0;
+        cn[s] = (!(fl[s] & 8) || a.per_j) ? no : 0.0;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            bq[s][q] = a.b[q][c];
+            if (idx < n) plane(q, 1)[idx] = a.x0[q][c];
+        }
+        if (idx < n) {
+            // k_rowsum_bound: sum of the couplings that have a neighbour, in offdiag's order
+            double sum = 0.0;
+            if (!(fl[s] & 1) || a.per_i) sum += w * 1.0;
+            if (!(fl[s] & 2) || a.per_i) sum += e * 1.0;
+            if (!(fl[s] & 4) || a.per_j) sum += so * 1.0;
+            if (!(fl[s] & 8) || a.per_j) sum += no * 1.0;
+            rho_loc = fmax(rho_loc, sum / d[s]);
+        }
+    }
+    int buf = 0;
+    // rho = max over the cells (a maximum: any order gives the same bits)
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rho_loc = fmax(rho_loc, __shfl_down(rho_loc, off, 64));
+        double *r = red + 4 * 16 * 2;
+        if ((tid & 63) == 0) r[tid >> 6] = rho_loc;
+        __syncthreads();              // (also publishes x_0 in the B planes)
+        double m = r[0];
+#pragma unroll
+        for (int k = 1; k < TAIL_NT / 64; ++k) m = fmax(m, r[k]);
+        rho_loc = m;
+    }
+    const double rho = rho_loc;
+    auto nbr = [&](const double *x, int s, int idx) {
+        const int f = fl[s];
+        const int iw = idx - 1 + ((f & 1) ? dwi : 0), ie = idx + 1 - ((f & 2) ? dwi : 0);
+        const int is = idx - ni + ((f & 4) ? dsj : 0), in = idx + ni - ((f & 8) ? dsj : 0);
+        double sum = 0.0;
+        sum += cw[s] * x[iw];
+        sum += ce[s] * x[ie];
+        sum += cs[s] * x[is];
+        sum += cn[s] * x[in];
+        return sum;
+    };
+    // one pass of k_cheb: x_k in xk, x_{k-1} in xm, x_{k+1} to xo (xo may be xm: own cell only); acc[q] += |r_k|^2
+    auto pass = [&](int wk, int wm, int wo, double c1, double c2, bool first, double (&acc)[2 * NB]) {
+#pragma unroll
+        for (int s = 0; s < CPT; ++s) {
+            const int idx = tid + s * TAIL_NT;
+            if (idx < n) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const double *xk = plane(q, wk);
+                    const double xc = xk[idx];
+                    const double r = bq[s][q] - (d[s] * xc - nbr(xk, s, idx));
+                    acc[q] += r * r;
+                    double step = c2 * (r / d[s]);
+                    if (first) acc[NB + q] += bq[s][q] * bq[s][q];
+                    else step += c1 * (xc - plane(q, wm)[idx]);
+                    plane(q, wo)[idx] = xc + step;
+                }
+            }
+        }
+    };
+    double acc[2 * NB];
+#pragma unroll
+    for (int q = 0; q < 2 * NB; ++q) acc[q] = 0.0;
+    // first pass: r_0, |b|^2, x_1 = x_0 + r_0 / D
+    pass(1, 1, 0, 0.0, 1.0, true, acc);
+    cheb_tail_sums<2 * NB>(acc, red, buf, tid);          // (its barrier publishes x_1)
+    double rr[NB], bb[NB];
+    int status = -1, kdone = 0;
+    int result = 1;                                      // plane B: x_0
+#pragma unroll
+    for (int q = 0; q < NB; ++q) { rr[q] = acc[q]; bb[q] = acc[NB + q]; }
+    for (int q = 0; q < NB; ++q) {
+        if (!(rr[q] == rr[q]) || !(bb[q] == bb[q])) { if (status < 0) status = 3; }
+        else if (bb[q] == 0.0 && rr[q] > 0.0) { if (status < 0) status = 0; }
+    }
+    if (status < 0 && (!(rho >= 0.0) || rho > a.rho_max)) status = 0;
+    auto done = [&](const double *r2) {
+        for (int q = 0; q < NB; ++q)
+            if (sqrt(r2[q]) > a.tol * sqrt(bb[q])) return false;
+        return true;
+    };
+    if (status < 0 && done(rr)) status = 1;              // x_0 already meets the test
+    if (status < 0) {
+        // iterations the Chebyshev bound asks for: 2 s^k / (1 + s^2k) <= tol |b| / |r_0|
+        const double sigma1 = rho > 1e-300 ? 1.0 / rho : 1e300;
+        const double sg = rho > 1e-300 ? sigma1 - sqrt(sigma1 * sigma1 - 1.0) : 0.0;
+        double need = 1.0;
+        for (int q = 0; q < NB; ++q)
+            if (rr[q] > 0.0) need = fmin(need, a.tol * sqrt(bb[q]) / sqrt(rr[q]));
+        int kpred = 1;
+        if (sg > 0.0) {
+            const double kp = log(need / 2.0) / log(sg);
+            kpred = kp > 1.0 ? (kp < 1.0e6 ? (int)ceil(kp) : 1000000) : 1;
+        }
+        if (kpred > a.cheb_max_iters || kpred > a.maxiter) status = 0;
+        if (status < 0) {
+            double rk = rho;
+            const int klimit = min(a.maxiter, kpred + 8 + kpred / 2);
+            for (int k = 1;; ++k) {
+                const int cur = (k & 1) ? 0 : 1, oth = cur ^ 1;       // x_k sits in A for odd k, in B for even k
+                const double rnew = 1.0 / (2.0 * sigma1 - rk);
+                double c1 = rnew * rk, c2 = 2.0 * rnew / rho;
+                if (rho < 1.0e-14) { c1 = 0.0; c2 = 1.0; }
+                rk = rnew;
+#pragma unroll
+                for (int q = 0; q < 2 * NB; ++q) acc[q] = 0.0;
+                pass(cur, oth, oth, c1, c2, false, acc);
+                if (k >= kpred || k >= klimit) {
+                    cheb_tail_sums<2 * NB>(acc, red, buf, tid);       // |r_k|^2 of the iterate the pass started from
+                    bool finite = true;
+                    for (int q = 0; q < NB; ++q) { rr[q] = acc[q]; finite = finite && rr[q] == rr[q]; }
+                    kdone = k;
+                    result = cur;
+                    if (!finite) { status = 3; break; }
+                    if (done(rr)) { status = 1; break; }
+                    if (k >= klimit) { status = 2; break; }
+                } else {
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    if (status == 1 || status == 2) {
+#pragma unroll
+        for (int s = 0; s < CPT; ++s) {
+            const int idx = tid + s * TAIL_NT;
+            if (idx < n) {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) a.x[q][g.cell(idx % ni, idx / ni)] = plane(q, result)[idx];
+            }
+        }
+    }
+    if (tid == 0) {
+        a.out[0] = (double)status;
+        a.out[1] = (double)kdone;
+        for (int q = 0; q < NB; ++q) { a.out[2 + q] = rr[q]; a.out[4 + q] = bb[q]; }
+        a.out[6] = rho;
+    }
+}
+
 // ------------------------------------------------------------------ fused marching multigrid kernels
 // One wavefront owns a column strip: lane = column, it marches down the rows of a segment.
 // Vertical neighbours stay in registers (sliding windows), horizontal neighbours come from
@@ -2800,6 +3004,65 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
     }
 }
 
+static int raise_tail_lds_limit(const void *kernel) {
+    CFD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_DOUBLES * (int)sizeof(double)));
+    return CFD_OK;
+}
+// The whole solve as one launch of k_cheb_tail (one rank, at most Ctx::cheb_tail_cells cells).  One host read afterwards
+// instead of two or three -- or none in a speculative iteration: status and residual sums wait in a device slot for the
+// iteration's closing read (spec_verify); anything but "solved" there repeats the iteration on the host-checked path, which
+// takes the fall-backs (BiCGStab) as before.
+constexpr int SPEC_CHEBT_OFF = 232;          // Ctx::scal: 8 doubles per solve, up to SPEC_CHEBT_MAX solves per iteration
+constexpr int CHEBT_OUT_OFF = 16;            // ... of a host-checked solve
+template <int NB>
+static int chebyshev_tail(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
+                          double tol, int maxiter, int *iters, double relres[2], double rms[2], int *used) {
+    const Geo g = op.g;
+    const long n = (long)g.ni * g.nj;
+    ChebTailArgs a{};
+    a.ci = op.ci; a.cj = op.cj; a.D = op.D; a.g = g; a.per_i = op.per_i; a.per_j = op.per_j;
+    for (int q = 0; q < NB; ++q) { a.b[q] = b[q]; a.x0[q] = x0[q]; a.x[q] = x[q]; }
+    a.tol = tol; a.rho_max = c->cheb_rho_max; a.maxiter = maxiter; a.cheb_max_iters = c->cheb_max_iters;
+    const bool spec = c->spec_on && c->spec_chebt.n < Ctx::SPEC_CHEBT_MAX;
+    a.out = c->scal + (spec ? SPEC_CHEBT_OFF + 8 * c->spec_chebt.n : CHEBT_OUT_OFF);
+    const size_t lds_bytes = ((size_t)2 * NB * n + 144) * sizeof(double);
+    static bool lds_limit_raised = false;
+    if (!lds_limit_raised) {
+        CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_cheb_tail<1, 1>)));
+        CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_cheb_tail<2, 1>)));
+        CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_cheb_tail<1, TAIL_CPT>)));
+        CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_cheb_tail<2, TAIL_CPT>)));
+        lds_limit_raised = true;
+    }
+    if (n <= TAIL_NT) hipLaunchKernelGGL((k_cheb_tail<NB, 1>), dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a);
+    else hipLaunchKernelGGL((k_cheb_tail<NB, TAIL_CPT>), dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a);
+    CFD_HIP(hipGetLastError());
+    c->kc[KC_CHEB_TAIL] += 1;
+    if (spec) {
+        Ctx::SpecChebT &sp = c->spec_chebt;
+        sp.nb[sp.n] = NB;
+        sp.momentum[sp.n] = op.D == c->ap;
+        sp.n += 1;
+        for (int q = 0; q < NB; ++q) { relres[q] = 0.0; if (rms) rms[q] = 0.0; }      // known at the closing read
+        *iters = c->stats.mom_iters;
+        *used = 1;
+        return CFD_OK;
+    }
+    double h[7];
+    CFD_TRY(read_scalars(c, CHEBT_OUT_OFF, 7, h));
+    const int status = (int)h[0];
+    if (status == 3) { set_error("momentum-like solve: non-finite right-hand side or residual"); return CFD_E_NUMERIC; }
+    *iters = (int)h[1];
+    *used = status;              // 0: not used, 1: solved, 2: best iterate in x, BiCGStab continues
+    if (status == 1) {
+        for (int q = 0; q < NB; ++q) {
+            relres[q] = h[4 + q] > 0.0 ? sqrt(h[2 + q] / h[4 + q]) : 0.0;
+            if (rms) rms[q] = sqrt(h[2 + q] / global_cells(c));
+        }
+    }
+    return CFD_OK;
+}
+
 // returns CFD_OK with *used = 0 when the system is not time-step dominated (caller falls back)
 template <int NB>
 static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double *const x[2], const double *const x0[2],
@@ -2807,6 +3070,8 @@ static int chebyshev_jacobi(Ctx *c, const OpDev &op, double *const b[2], double 
     *used = 0;
     if (!x0 || !c->use_chebyshev) return CFD_OK;
     const Geo g = op.g;
+    if (c->cheb_tail && c->comm.nranks == 1 && !g.cutlo && !g.cuthi && (long)g.ni * g.nj <= c->cheb_tail_cells)
+        return chebyshev_tail<NB>(c, op, b, x, x0, tol, maxiter, iters, relres, rms, used);
     const Tiling T = tiling(g);
     const dim3 grid(T.blocks), blk = block2d();
     hipStream_t st = c->stream;
@@ -3404,10 +3669,6 @@ static TailDev tail_launch_args(const Ctx *c, const TailArgs &built) {
     for (int q = 0; q < a.nom; ++q) a.om[q] = c->om_at(q);
     a.om_coarse = c->om_mean(); a.gamma = c->mg_gamma;
     return a;
-}
-static int raise_tail_lds_limit(const void *kernel) {
-    CFD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_DOUBLES * (int)sizeof(double)));
-    return CFD_OK;
 }
 
 static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double **zout, int *dot_blocks,
@@ -4185,6 +4446,17 @@ int spec_verify(Ctx *c, double *res, bool *ok) {
             if (res) res[1 + q] = sqrt(taken / global_cells(c));
             if (earliest >= 0) c->cheb_plan.retire_k[q] = earliest;      // the next replay leaves at the first iterate that was good enough
         }
+    }
+    const Ctx::SpecChebT &st = c->spec_chebt;
+    for (int s = 0; s < st.n; ++s) {
+        const double *slot = h + SPEC_CHEBT_OFF + 8 * s;
+        if ((int)slot[0] != 1) { *ok = false; continue; }          // a fall-back or an error: the host-checked path takes it
+        if (!st.momentum[s]) continue;
+        for (int q = 0; q < st.nb[s]; ++q) {
+            c->stats.mom_relres[q] = slot[4 + q] > 0.0 ? sqrt(slot[2 + q] / slot[4 + q]) : 0.0;
+            if (res) res[1 + q] = sqrt(slot[2 + q] / global_cells(c));
+        }
+        c->stats.mom_iters = (int)slot[1];
     }
     const Ctx::SpecPcg &sp = c->spec_pcg;
     for (int s = 0; s < sp.n; ++s) {

@@ -436,6 +436,7 @@ int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, doub
  * face coefficients rounded to single precision -- the Krylov operator stays double, the solution is unchanged),
  * "mg_semi" (1 / 0: stretched meshes are cycled by zebra whole-line relaxation along i with semi-coarsening along j /
  * by the alternating block line smoother with full coarsening; one rank, frozen operator, lines of at most 8192 cells),
+ * "cheb_tail" / "cheb_tail_cells" (1 / 0, cell limit: Chebyshev transport solves of small meshes in one launch),
  * "pcg_tail" (1 / 0: the pressure solve of a mesh whose hierarchy fits one workgroup's LDS is one launch with the
  * stopping test on the device / the launch-per-phase loop), "pcg_tail_cells" (cell limit of that path), "march_ls_model",
  * "speculate" (-1 / 0 / 1: inner iterations with one host read at their end, see cfd_kernel_counts; auto = contexts of
@@ -451,8 +452,8 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
  * correction / flux kernel, [15] levels of the semi-coarsened line multigrid, [16] inner iterations that ran speculatively
  * (option "speculate": solves replay the previous iteration's schedule, one host read at the iteration's end, stopping
  * tests evaluated then), [17] of those, iterations whose test failed and that were repeated host-checked, [18] pressure
- * solves that were ONE launch (k_pcg_tail: the whole MG-PCG solve of a mesh whose hierarchy fits one workgroup's LDS).
- * n <= 19 entries are written.  No counterpart in the reference.  */
+ * solves that were ONE launch (k_pcg_tail: the whole MG-PCG solve of a mesh whose hierarchy fits one workgroup's LDS),
+ * [19] transport solves (momentum, k / omega) that were ONE launch (k_cheb_tail).  n <= 20 entries are written.  No counterpart in the reference.  */
 int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset);
 /* Host-side cost of the calls so far, process wide: out[0] = kernel launches, out[1] = blocking stream
  * synchronisations the library issued (each one idles the GPU while the host reads a scalar).  They bound the step

@@ -771,3 +771,58 @@ def test_whole_pressure_solve_reports_a_solve_that_runs_out_of_iterations():
             assert dev.kernel_counts()["pcg_tail"] > 0 if one else dev.kernel_counts()["pcg_tail"] == 0
             dev.close()
         assert counts[1] == counts[0] and counts[1][0] > 0 and counts[1][1] == 2, counts
+
+
+CHEB_TAIL_CASES = {
+    "periodic_16x12": (lambda: cases.lam_channel(16, 12, steps=4), None),
+    "periodic_31x17": (lambda: cases.lam_channel(31, 17, steps=4), None),
+    "periodic_32x32": (lambda: cases.channel_forced(n=32, steps=3), cases.perturbed_parabola),
+    "komega_32x32": (lambda: cases.channel_forced(n=32, steps=3, turbulent=True), cases.perturbed_parabola),   # k / omega solves too
+    "inlet_outlet_40x24": (lambda: cases.inlet_outlet_channel(40, 24, steps=3), None),
+    "inlet_outlet_50x52": (lambda: cases.inlet_outlet_channel(50, 52, steps=3), None),    # four cells per thread
+    "couette_piso_8x10": (lambda: cases.couette_piso(8, 10, steps=4), cases.perturbed_rest),
+    "half_cylinder_12x16": (lambda: cases.half_cylinder(nr=12, nt=16, steps=3), None),
+    "channel_komega_5x20": (lambda: cases.channel_komega_5x20(steps=6, tol=cases.TIGHT), cases.ramp_initial_u),
+    "channel_sst_5x20": (lambda: cases.channel_komega_5x20(steps=6, tol=cases.TIGHT, model="sst"), cases.ramp_initial_u),
+}
+
+
+@pytest.mark.parametrize("speculate", [0, 1])
+@pytest.mark.parametrize("name", list(CHEB_TAIL_CASES))
+def test_whole_transport_solve_in_one_launch(name, speculate, tmp_path):
+    """k_cheb_tail (row-sum bound, first pass, the iteration count the Chebyshev bound predicts, the passes and the
+    stopping test in ONE launch, iterates in LDS) against the one-iteration-per-launch form it restates: the iterates are
+    the same bits, only the residual sums are taken in another order, so the fields agree to rounding; fall-backs to
+    BiCGStab (systems that are not time-step dominated) are taken alike."""
+    from cfd_amd import mesh as hip_mesh
+    from cfd_amd import solver as hip_solver
+    builder, fixup = CHEB_TAIL_CASES[name]
+    runs = []
+    for one in (1, 0):
+        cfg, mp, kind = builder()
+        work = tmp_path / f"c{one}"
+        gen = hip_mesh.generate_rect_mesh if kind == "rect" else hip_mesh.generate_annulus_mesh
+        cfg["mesh"] = {"generator": gen, "params": mp, "path": work / "mesh" / "mesh.npz"}
+        cfg["paths"] = {"case_dir": work, "mesh_dir": work / "mesh", "states_dir": work / "states", "post_dir": work / "postproc"}
+        mesh = hip_mesh.make_mesh(cfg["mesh"])
+        if fixup is not None:
+            fixup(cfg, mesh)
+        cfg["solver"]["turbulence_solver"] = {"tol": TRANSPORT_TOL, "maxiter": 2000}
+        cfg["solver"]["momentum"]["tol"] = TRANSPORT_TOL
+        # the launch-per-iteration form of the comparison: the fused form (from 16 cells per side) retires a right-hand side
+        # at the first iterate that meets the test, which is another -- equally valid -- iterate
+        cfg["solver"]["tuning"] = {"mg_line": 0, "cheb_tail": one, "speculate": speculate, "fused_min_cheb": 4096}
+        fields, step, time = hip_solver.run_case(cfg)
+        runs.append((fields, dict(hip_solver.LAST_RUN)))
+    (f1, last1), (f0, last0) = runs
+    k1, k0 = last1["kernel_counts"], last0["kernel_counts"]
+    assert k0["cheb_tail"] == 0
+    assert last1["stats"]["mom_solver"] == last0["stats"]["mom_solver"], (last1["stats"], last0["stats"])
+    if last0["stats"]["mom_solver"] == "chebyshev":
+        assert k1["cheb_tail"] > 0 and k1["cheb1"] == 0 and k0["cheb1"] > 0, (k1, k0)
+        assert last1["stats"]["mom_iters"] == last0["stats"]["mom_iters"]
+    unorm = max(np.linalg.norm(f0["u"].ravel()), 1e-300)
+    for key in f0:
+        err = np.linalg.norm((mask_corners(f1[key]) - mask_corners(f0[key])).ravel())
+        den = np.linalg.norm(mask_corners(f0[key]).ravel())
+        assert err <= 1e-12 * den + 1e-14 * unorm, (key, err, den)

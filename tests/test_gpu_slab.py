@@ -188,4 +188,7 @@ def test_wall_friction_on_slabs(case, world, tmp_path):
         assert np.abs(a - b).max() <= 1e-9 * max(np.abs(a).max(), 1e-300), side      # fields equal to the solver tolerance
         # (the mean over an inlet plane cancels to rounding: measured against the largest face value)
         assert abs(float(one[f"{side}_tau_avg"]) - float(many[f"{side}_tau_avg"])) <= 1e-9 * np.abs(a).max() + 1e-300, side
-    assert np.allclose(one["res"], many["res"], rtol=1e-6, atol=1e-14)
+    # continuity sums equal to rounding; the momentum residuals are what each run's solver stopped at (one rank: the one-launch
+    # Chebyshev solve runs the count its bound predicts, the slabs' fused form leaves at the first iterate that meets 1e-13)
+    assert np.allclose(one["res"][:, 0], many["res"][:, 0], rtol=1e-6, atol=1e-14)
+    assert np.all(one["res"][:, 1:] <= 1e-12) and np.all(many["res"][:, 1:] <= 1e-12)
