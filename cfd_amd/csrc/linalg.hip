@@ -1091,8 +1091,8 @@ __device__ __forceinline__ double tail_block_sum(double v, double *red, int &buf
     if ((tid & 63) == 0) r[tid >> 6] = w;
     __syncthreads();
     double tot = 0.0;
-#pragma unroll
-    for (int k = 0; k < TAIL_NT / 64; ++k) tot += r[k];
+    const int nw = (int)blockDim.x >> 6;          // (a small mesh is launched with as many waves as it has cells for)
+    for (int k = 0; k < nw; ++k) tot += r[k];
     buf ^= 1;        // the next sum writes the other half: no barrier between these reads and those writes
     return tot;
 }
@@ -1231,8 +1231,8 @@ __device__ __forceinline__ void cheb_tail_sums(double (&v)[NQ], double *red, int
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         double tot = 0.0;
-#pragma unroll
-        for (int k = 0; k < TAIL_NT / 64; ++k) tot += r[q * 16 + k];
+        const int nw = (int)blockDim.x >> 6;
+        for (int k = 0; k < nw; ++k) tot += r[q * 16 + k];
         v[q] = tot;
     }
     buf ^= 1;
@@ -1287,8 +1287,8 @@ __global__ __launch_bounds__(TAIL_NT) void k_cheb_tail(ChebTailArgs a) {
         if ((tid & 63) == 0) r[tid >> 6] = rho_loc;
         __syncthreads();              // (also publishes x_0 in the B planes)
         double m = r[0];
-#pragma unroll
-        for (int k = 1; k < TAIL_NT / 64; ++k) m = fmax(m, r[k]);
+        const int nw = (int)blockDim.x >> 6;
+        for (int k = 1; k < nw; ++k) m = fmax(m, r[k]);
         rho_loc = m;
     }
     const double rho = rho_loc;
@@ -3004,6 +3004,10 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
     }
 }
 
+static inline int tail_threads(long cells) {
+    const long t = (cells + 63) / 64 * 64;
+    return (int)(t < 64 ? 64 : (t > TAIL_NT ? TAIL_NT : t));
+}
 static int raise_tail_lds_limit(const void *kernel) {
     CFD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS_DOUBLES * (int)sizeof(double)));
     return CFD_OK;
@@ -3034,7 +3038,7 @@ static int chebyshev_tail(Ctx *c, const OpDev &op, double *const b[2], double *c
         CFD_TRY(raise_tail_lds_limit(reinterpret_cast<const void *>(&k_cheb_tail<2, TAIL_CPT>)));
         lds_limit_raised = true;
     }
-    if (n <= TAIL_NT) hipLaunchKernelGGL((k_cheb_tail<NB, 1>), dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a);
+    if (n <= TAIL_NT) hipLaunchKernelGGL((k_cheb_tail<NB, 1>), dim3(1), dim3(tail_threads(n)), lds_bytes, c->stream, a);
     else hipLaunchKernelGGL((k_cheb_tail<NB, TAIL_CPT>), dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a);
     CFD_HIP(hipGetLastError());
     c->kc[KC_CHEB_TAIL] += 1;
@@ -4161,7 +4165,8 @@ static int pcg_tail_solve(Ctx *c, const double *b, double *x, double tol, int ma
         lds_limit_raised = true;
     }
     const size_t lds_bytes = (size_t)pcg_tail_lds_doubles(a.total, top, a.ncache) * sizeof(double);
-    if (top <= TAIL_NT) hipLaunchKernelGGL(k_pcg_tail<1>, dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a, pa, b, x, out);
+    // one cell per thread: as many waves as the finest level has cells for (a 5 x 20 mesh: two waves meet at the barriers, not sixteen)
+    if (top <= TAIL_NT) hipLaunchKernelGGL(k_pcg_tail<1>, dim3(1), dim3(tail_threads(top)), lds_bytes, c->stream, a, pa, b, x, out);
     else hipLaunchKernelGGL(k_pcg_tail<TAIL_CPT>, dim3(1), dim3(TAIL_NT), lds_bytes, c->stream, a, pa, b, x, out);
     CFD_HIP(hipGetLastError());
     c->kc[KC_PCG_TAIL] += 1;
