@@ -389,6 +389,8 @@ struct Ctx {
         int nb[SPEC_CHEBT_MAX] = {};
         bool momentum[SPEC_CHEBT_MAX] = {};
     } spec_chebt;
+    bool chebt_good[2] = {false, false};   // the last host-checked one-launch solve (momentum / other) ended "solved"
+    bool ptail_good = false;               // the last host-checked one-launch pressure solve converged
     int cheb_tail = 1;                 // 1: transport solves of meshes of at most cheb_tail_cells cells are one launch (k_cheb_tail)
     int cheb_tail_cells = 2800;        // (the size up to which the pressure solve is one launch as well)
     int cf_agreed = -1;                // slab ranks' common answer to correct_flux_ok (-1: not asked yet)

@@ -3027,7 +3027,10 @@ static int chebyshev_tail(Ctx *c, const OpDev &op, double *const b[2], double *c
     a.ci = op.ci; a.cj = op.cj; a.D = op.D; a.g = g; a.per_i = op.per_i; a.per_j = op.per_j;
     for (int q = 0; q < NB; ++q) { a.b[q] = b[q]; a.x0[q] = x0[q]; a.x[q] = x[q]; }
     a.tol = tol; a.rho_max = c->cheb_rho_max; a.maxiter = maxiter; a.cheb_max_iters = c->cheb_max_iters;
-    const bool spec = c->spec_on && c->spec_chebt.n < Ctx::SPEC_CHEBT_MAX;
+    // (speculative only after a host-checked solve of this kind of system ended "solved": a system that keeps going to
+    // BiCGStab would otherwise repeat every iteration)
+    const int kind = op.D == c->ap ? 0 : 1;
+    const bool spec = c->spec_on && c->spec_chebt.n < Ctx::SPEC_CHEBT_MAX && c->chebt_good[kind];
     a.out = c->scal + (spec ? SPEC_CHEBT_OFF + 8 * c->spec_chebt.n : CHEBT_OUT_OFF);
     const size_t lds_bytes = ((size_t)2 * NB * n + 144) * sizeof(double);
     static bool lds_limit_raised = false;
@@ -3055,6 +3058,7 @@ static int chebyshev_tail(Ctx *c, const OpDev &op, double *const b[2], double *c
     double h[7];
     CFD_TRY(read_scalars(c, CHEBT_OUT_OFF, 7, h));
     const int status = (int)h[0];
+    c->chebt_good[kind] = status == 1;
     if (status == 3) { set_error("momentum-like solve: non-finite right-hand side or residual"); return CFD_E_NUMERIC; }
     *iters = (int)h[1];
     *used = status;              // 0: not used, 1: solved, 2: best iterate in x, BiCGStab continues
@@ -4152,7 +4156,7 @@ static int pcg_tail_solve(Ctx *c, const double *b, double *x, double tol, int ma
     const TailDev a = tail_launch_args(c, c->ptail);
     const Geo &g = a.g0;
     const long top = (long)g.ni * g.nj;
-    const bool spec = c->spec_on && c->spec_pcg.n < 4;
+    const bool spec = c->spec_on && c->spec_pcg.n < 4 && c->ptail_good;     // (after a host-checked solve that converged)
     PcgTailArgs pa{};
     pa.tol = tol; pa.pin_value = c->pin_value; pa.maxiter = maxiter; pa.ns_active = c->p_ns_active ? 1 : 0;
     pa.pin_idx = c->pin_i >= 0 ? c->pin_j * g.ni + c->pin_i : -1;
@@ -4187,6 +4191,7 @@ static int pcg_tail_solve(Ctx *c, const double *b, double *x, double tol, int ma
     *iters = (int)h[0];
     *relres = h[2] > 0.0 ? sqrt(h[1] / h[2]) : 0.0;
     c->p_iters_hint = *iters;
+    c->ptail_good = sqrt(h[1]) <= tol * sqrt(h[2]);
     return CFD_OK;
 }
 
@@ -4455,7 +4460,11 @@ int spec_verify(Ctx *c, double *res, bool *ok) {
     const Ctx::SpecChebT &st = c->spec_chebt;
     for (int s = 0; s < st.n; ++s) {
         const double *slot = h + SPEC_CHEBT_OFF + 8 * s;
-        if ((int)slot[0] != 1) { *ok = false; continue; }          // a fall-back or an error: the host-checked path takes it
+        if ((int)slot[0] != 1) {          // a fall-back or an error: the host-checked path takes it
+            *ok = false;
+            c->chebt_good[st.momentum[s] ? 0 : 1] = false;
+            continue;
+        }
         if (!st.momentum[s]) continue;
         for (int q = 0; q < st.nb[s]; ++q) {
             c->stats.mom_relres[q] = slot[4 + q] > 0.0 ? sqrt(slot[2 + q] / slot[4 + q]) : 0.0;
@@ -4469,7 +4478,7 @@ int spec_verify(Ctx *c, double *res, bool *ok) {
         if (sp.hint[s] < 0) {
             // k_pcg_tail: the device applied the stopping test; not met means the solve ran into maxiter
             const double bb = slot[8], rr = slot[1];
-            if (!(bb == bb) || !(rr == rr) || !(sqrt(rr) <= sp.tol[s] * sqrt(bb))) { *ok = false; continue; }
+            if (!(bb == bb) || !(rr == rr) || !(sqrt(rr) <= sp.tol[s] * sqrt(bb))) { *ok = false; c->ptail_good = false; continue; }
             c->stats.p_relres = bb > 0.0 ? sqrt(rr / bb) : 0.0;
             c->stats.p_iters = (int)slot[0];
             c->p_iters_hint = (int)slot[0];
