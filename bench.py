@@ -401,8 +401,10 @@ def rehearse_launch(world, rank, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the workload's solver schedule settles around outer step 11 (the perturbed start needs one more four-iteration
+    # momentum launch per solve until then: 43.4 against 42.1 ms per step), so the default warm-up runs past it
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--size", type=int, default=8192, help="cells per side of the channel (strong scaling: of the whole "
                     "channel, split over the GPUs; --weak: per GPU)")
     ap.add_argument("--turbulent", action="store_true", help="k-omega variant of the workload")
