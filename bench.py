@@ -539,6 +539,7 @@ def main():
     dev.probe(L.PROBE_ALL if probe_id < 0 else probe_id)
     comm0 = dev.comm_counts()
     phase0 = dev.comm_counts_by_phase()
+    host0 = dev.host_counters()
     barrier()
     t0 = time.perf_counter()
     step_marks = []
@@ -571,6 +572,7 @@ def main():
         n_probe, probe_us, probe_bpc = dev.probe_read(with_bytes=True)
     dev.probe(-1)
     comm1, phase1 = dev.comm_counts(), dev.comm_counts_by_phase()
+    host1 = dev.host_counters()
     # ---- outside the timed region: per-phase device times of two more steps (event pairs with a host
     # sync per phase, which is why they are not collected inside the timed steps) and a plain
     # device-to-device copy of one plane as the streaming reference figure of this GPU
@@ -685,6 +687,11 @@ def main():
                            [(a - b) / args.steps for a, b in zip(comm1, comm0)])),
                        "collectives_per_step_by_phase": None if dev.comm is None else {
                            ph: [(a - b) / args.steps for a, b in zip(phase1[ph], phase0[ph])] for ph in phase1},
+                       # host side of the timed steps: kernel launches and blocking stream synchronisations of this rank
+                       # (the probe's own event records are not counted; speculative iterations -- kernel_launch_counts --
+                       # end with one read each)
+                       "host_per_step": {"kernel_launches": (host1[0] - host0[0]) / args.steps,
+                                         "stream_synchronisations": (host1[1] - host0[1]) / args.steps},
                        "inner_iterations": args.max_iter,
                        "mean_momentum_iters": float(it[:, 0].mean()), "mean_pressure_iters": float(it[:, 1].mean()),
                        "mean_komega_iters": float(it[:, 2].mean()) if args.turbulent else 0.0,

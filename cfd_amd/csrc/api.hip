@@ -1028,9 +1028,12 @@ int cfd_compute_dt(cfd_ctx *ctx, int use_cfl, double cfl, int use_cfl_diff, doub
 // (or the replay itself gave up), the iteration is undone -- c->cur back: u, v, p of the start are untouched in their
 // half of the ping-pong planes, everything else an iteration writes is recomputed -- and repeated host-checked.
 static int run_iteration(Ctx *c, double *res, const std::function<int()> &body) {
-    // auto (-1): where a host read costs a noticeable share of the step.  On a large slab the reads are < 1 % of the step
-    // while one repeated iteration costs half a step, so the host-checked path stays the default there.
-    const bool want = c->speculate > 0 || (c->speculate < 0 && (long)c->g.ni * c->g.nj <= Ctx::SPEC_AUTO_CELLS);
+    // auto (-1): where a host read costs a noticeable share of the step.  On a large single-rank mesh the reads are < 1 % of
+    // the step while one repeated iteration costs half a step, so the host-checked path stays the default there.  On j-slabs
+    // every host read also waits for an all-reduce over the ranks with the GPU idle, and the slab's kernels are 1 / nranks
+    // as long: four times the limit (the 8192^2 channel on 4 and 8 ranks).
+    const long spec_cells = c->comm.nranks > 1 ? Ctx::SPEC_AUTO_CELLS_SLAB : Ctx::SPEC_AUTO_CELLS;
+    const bool want = c->speculate > 0 || (c->speculate < 0 && (long)c->g.ni * c->g.nj <= spec_cells);
     const bool spec = want && c->host_lag && c->march_flux && c->freeze_pressure && c->p_built && c->spec_age < Ctx::SPEC_RENEW;
     const int cur0 = c->cur;
     c->spec_cheb = Ctx::SpecCheb{};

@@ -356,8 +356,8 @@ struct Ctx {
     // means a solve needed more iterations than last time: the iteration is undone (its inputs are still in the other
     // half of the ping-pong planes) and repeated on the host-checked path, which also renews the schedule.  Every
     // SPEC_RENEW-th iteration runs host-checked anyway so that the schedule can shrink.
-    int speculate = -1;                // -1: on for contexts of <= SPEC_AUTO_CELLS cells, 0 / 1: off / on
-    static constexpr long SPEC_AUTO_CELLS = 1L << 22;
+    int speculate = -1;                // -1: on for contexts of <= SPEC_AUTO_CELLS cells (j-slabs: SPEC_AUTO_CELLS_SLAB), 0 / 1: off / on
+    static constexpr long SPEC_AUTO_CELLS = 1L << 22, SPEC_AUTO_CELLS_SLAB = 1L << 24;     // cells of this context (a slab: its own rows)
     bool spec_on = false;              // inside a speculative iteration
     int spec_age = 0;                  // speculative iterations since the last host-checked one
     static constexpr int SPEC_RENEW = 48;
