@@ -397,6 +397,7 @@ struct Ctx {
     bool bc_fresh = false;             // the ghosts of u, v, p [bc_cur] are those of k_flow_bc + exchange on the current values
     int bc_cur = -1, skip_fresh_bc = 1;
     bool mesh_halo2 = false;           // metric planes hold the neighbour slab's rows beyond the cuts (launch_correct_flux)
+    int pcg_xsum = 1;                  // fused MG-PCG: x summed from the kept directions when the solve ends (k_cg_xsum) instead of updated every step
     int fuse_correct = 1;              // correction + boundary fill + closing flux pass in one marching kernel where correct_flux_ok()
     int per_i = 0, per_j = 0, wrap_p_i = 0, wrap_p_j = 0;
     int32_t *pmask[4] = {nullptr, nullptr, nullptr, nullptr};

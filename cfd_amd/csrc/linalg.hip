@@ -3995,16 +3995,22 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 // FIRST / XZERO (first / second step of a solve: no p_old / no x to read) are template arguments and the diagonal is
 // formed where a row is consumed: a wave-uniform branch around a load, or arithmetic on a row's coefficients right
 // after its loads were issued, makes the wave wait for the row it has just asked for (the prefetch then hides nothing).
-template <int WPB, bool FIRST, bool XZERO, bool ZF = false>
+// NOX (option pcg_xsum, default): the step leaves x alone.  Every direction p_k of the solve stays in a plane of its own
+// (a ring of CG_RING planes) and alpha_k in a device slot, and x = sum_k alpha_k p_k is summed once, in the order the
+// updates would have been applied, when the solve ends or the ring is full (k_cg_xsum): a five-iteration solve reads
+// five planes and writes one instead of reading and writing x in every step (-16 B per cell and step from the third).
+// `alpha_out` (NOX, not the first step) receives alpha_prev.
+template <int WPB, bool FIRST, bool XZERO, bool ZF = false, bool NOX = false>
 __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen,
                                                     const double *z, const double *pold, double *pnew, double *q, double *x, double *partials,
-                                                    int nts) {
+                                                    int nts, double *alpha_out) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const size_t P = g.pitch;
-    constexpr bool first = FIRST, xzero = XZERO;
+    constexpr bool first = FIRST, xzero = XZERO || NOX;
     const double beta = first ? 0.0 : safe_div(s->rz[gen], s->rz[gen ^ 1]);
     const double alpha_prev = first ? 0.0 : safe_div(s->rz[gen ^ 1], s->pq);
+    if (NOX && !first && blockIdx.x == 0 && threadIdx.x == 0) alpha_out[0] = alpha_prev;
     double dot = 0.0;
     constexpr bool LOCK = WPB > 4;
     const int ngroups = (mg.nstrips + WPB - 1) / WPB;
@@ -4063,7 +4069,7 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
                 const double qv = d_b * pb - (cw_b * pl + ce_b * pr + cs_b * pa + cn_b * pc);
                 store_stream(pnew + cell_b, pb, nts);
                 store_stream(q + cell_b, qv, nts);
-                if (!first) store_stream(x + cell_b, xv_b + alpha_prev * po_b, nts);
+                if (!first && !NOX) store_stream(x + cell_b, xv_b + alpha_prev * po_b, nts);
                 dot += pb * qv;
             }
             pa = pb; pb = pc; po_b = po_c; xv_b = xv_c;
@@ -4119,6 +4125,46 @@ __global__ void k_cg_xlast(Geo g, Tiling T, const CgScal *s, int gen, int xzero,
         const size_t c = g.cell(i, j);
         x[c] = ((xzero ? 0.0 : x[c]) + alpha * p[c]) + sh;
     }
+}
+// x = (x +) sum_k alpha_k p_k over the n <= CG_RING direction planes a solve has left (option pcg_xsum, see k_cg_pq<.., NOX>),
+// added in iteration order with the expressions of the stepwise updates (0 + a_0 p_0, + a_1 p_1, ..., + shift: the same bits).
+// alpha_k of all but the last direction wait in ahist[k]; the last one is still rz / pq in the solver's scalars.
+constexpr int CG_RING = 6;
+constexpr int CG_AHIST_OFF = 48;          // Ctx::scal slots [48, 48 + CG_RING)
+struct XsumArgs {
+    const double *p[CG_RING];
+    int n, from_x;
+};
+__device__ __forceinline__ void xsum_alphas(const CgScal *s, int gen_last, const XsumArgs &a, const double *ahist, double (&al)[CG_RING]) {
+    const double last = safe_div(s->rz[gen_last], s->pq);
+#pragma unroll
+    for (int k = 0; k < CG_RING; ++k) al[k] = k < a.n - 1 ? ahist[k] : last;
+}
+__global__ void k_cg_xsum(Geo g, Tiling T, const CgScal *s, int gen_last, XsumArgs a, const double *ahist, const double *shift, double *x) {
+    double al[CG_RING];
+    xsum_alphas(s, gen_last, a, ahist, al);
+    const double sh = shift ? shift[0] : 0.0;
+    TILE_LOOP(g, T) {
+        const size_t c = g.cell(i, j);
+        double acc = a.from_x ? x[c] : 0.0;
+#pragma unroll
+        for (int k = 0; k < CG_RING; ++k)
+            if (k < a.n) acc = acc + al[k] * a.p[k][c];
+        x[c] = acc + sh;
+    }
+}
+// nullspace form with pcg_xsum: the shift from the solution at the reference cell, summed like k_cg_xsum does
+__global__ void k_ns_shift_sum(Geo g, int pi, int pj, double value, const CgScal *s, int gen_last, XsumArgs a, const double *ahist,
+                               const double *x, double *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double al[CG_RING];
+    xsum_alphas(s, gen_last, a, ahist, al);
+    const size_t c = g.cell(pi, pj);
+    double acc = a.from_x ? x[c] : 0.0;
+#pragma unroll
+    for (int k = 0; k < CG_RING; ++k)
+        if (k < a.n) acc = acc + al[k] * a.p[k][c];
+    out[0] = value - acc;
 }
 // nullspace form: the constant that moves the solution to the reference value at the reference cell;
 // with_p: the last x += alpha p is still owed (fused path)
@@ -4208,6 +4254,28 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     // fused direction step: marching kernel, p ping-pongs between two planes
     const bool fused = c->mg_fused && g.ni >= c->fused_min_pcg && g.nj >= c->fused_min_pcg;
     double *pbuf[2] = {c->kry[2], c->kry[6]};
+    // pcg_xsum: the directions of the solve stay in a ring of planes and x is summed from them at the end (k_cg_pq<.., NOX>);
+    // beside kry[2] and kry[6] the ring takes Chebyshev / transport work planes, which idle during a pressure solve (the
+    // test entry points hand in kry[11] / kry[12] as b and x: whatever the caller uses is left out; kry[10] keeps the saved
+    // right-hand side of the nearly-symmetric regime)
+    const bool xsum = fused && c->pcg_xsum;
+    double *pring[CG_RING];
+    {
+        const int cand[9] = {2, 6, 7, 8, 9, 11, 12, 13, 14};
+        int n = 0;
+        for (int q = 0; q < 9 && n < CG_RING; ++q)
+            if (c->kry[cand[q]] != b && c->kry[cand[q]] != x) pring[n++] = c->kry[cand[q]];
+    }
+    double *ahist = c->scal + CG_AHIST_OFF;
+    bool x_started = false;            // x holds the sum of the directions of earlier ring fills
+    // planes 0 .. n-1 of the ring = the directions p_{it-n} .. p_{it-1}, whose last alpha is still rz[(it-1) & 1] / pq
+    auto ring_args = [&](int it_done) {
+        XsumArgs a{};
+        a.n = (it_done - 1) % CG_RING + 1;
+        a.from_x = x_started ? 1 : 0;
+        for (int k = 0; k < CG_RING; ++k) a.p[k] = pring[k];
+        return a;
+    };
     MarchGeo mgeo = march_geo(g);
     mgeo.nstrips = (g.ni + 61) / 62;
     mgeo.xcd = c->xcd_map;
@@ -4293,8 +4361,16 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             CFD_TRY(finish_to(c, T.blocks, 1, CG_OFF_OF(rz[gen])));
         }
         if (fused) {
-            double *pold = pbuf[gen ^ 1];
-            p = pbuf[gen];
+            double *pold = xsum ? pring[(it + CG_RING - 1) % CG_RING] : pbuf[gen ^ 1];
+            p = xsum ? pring[it % CG_RING] : pbuf[gen];
+            if (xsum && it > 0 && it % CG_RING == 0) {
+                // the ring is full: its directions go into x before the first plane takes the next one
+                c->probe_begin(12);
+                hipLaunchKernelGGL(k_cg_xsum, grid, blk, 0, st, g, T, S, (it - 1) & 1, ring_args(it), ahist, (const double *)nullptr, x);
+                c->probe_end(12, 8.0 * (CG_RING + 1 + (x_started ? 1 : 0)));
+                CFD_HIP(hipGetLastError());
+                x_started = true;
+            }
             if (zf && (g.cutlo || g.cuthi) && c->comm.nranks > 1) {
                 Geo gz = g;
                 gz.pitch /= 2;                     // rows of half the bytes
@@ -4304,28 +4380,37 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
                 CFD_TRY(halo_exchange(c, g, 1, z, it == 0 ? nullptr : pold));
             }
             c->probe_begin(0);
-#define LAUNCH_CG_PQ(FIRST, XZERO, ZF)                                                                                        \
+#define LAUNCH_CG_PQ(FIRST, XZERO, ZF, NOX)                                                                                   \
     do {                                                                                                                      \
+        double *aout = ahist + (it + CG_RING - 1) % CG_RING;                                                                  \
         if (wide == 8)                                                                                                        \
-            hipLaunchKernelGGL((k_cg_pq<8, FIRST, XZERO, ZF>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
-                               c->partials, c->nts(g));                                                                       \
+            hipLaunchKernelGGL((k_cg_pq<8, FIRST, XZERO, ZF, NOX>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
+                               c->partials, c->nts(g), aout);                                                                 \
         else                                                                                                                  \
-            hipLaunchKernelGGL((k_cg_pq<4, FIRST, XZERO, ZF>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
-                               c->partials, c->nts(g));                                                                       \
+            hipLaunchKernelGGL((k_cg_pq<4, FIRST, XZERO, ZF, NOX>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
+                               c->partials, c->nts(g), aout);                                                                 \
     } while (0)
-            if (zf) {
-                if (it == 0) LAUNCH_CG_PQ(true, false, true);
-                else if (it == 1) LAUNCH_CG_PQ(false, true, true);
-                else LAUNCH_CG_PQ(false, false, true);
+            if (xsum) {
+                if (zf) {
+                    if (it == 0) LAUNCH_CG_PQ(true, false, true, true);
+                    else LAUNCH_CG_PQ(false, false, true, true);
+                } else {
+                    if (it == 0) LAUNCH_CG_PQ(true, false, false, true);
+                    else LAUNCH_CG_PQ(false, false, false, true);
+                }
+            } else if (zf) {
+                if (it == 0) LAUNCH_CG_PQ(true, false, true, false);
+                else if (it == 1) LAUNCH_CG_PQ(false, true, true, false);
+                else LAUNCH_CG_PQ(false, false, true, false);
             } else {
-                if (it == 0) LAUNCH_CG_PQ(true, false, false);
-                else if (it == 1) LAUNCH_CG_PQ(false, true, false);
-                else LAUNCH_CG_PQ(false, false, false);
+                if (it == 0) LAUNCH_CG_PQ(true, false, false, false);
+                else if (it == 1) LAUNCH_CG_PQ(false, true, false, false);
+                else LAUNCH_CG_PQ(false, false, false, false);
             }
 #undef LAUNCH_CG_PQ
             // algorithmic bytes: z, c_i, c_j read, p', q written (40); + p_old from the second step (48 -> with the x store 56);
-            // + the x read from the third (64)
-            c->probe_end(0, (it == 0 ? 40.0 : (it == 1 ? 56.0 : 64.0)) - (zf ? 4.0 : 0.0));
+            // + the x read from the third (64); pcg_xsum: 40 / 48, x is not touched
+            c->probe_end(0, (xsum ? (it == 0 ? 40.0 : 48.0) : (it == 0 ? 40.0 : (it == 1 ? 56.0 : 64.0))) - (zf ? 4.0 : 0.0));
             c->kc[KC_CG_PQ] += 1;
             CFD_HIP(hipGetLastError());
             CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));
@@ -4396,7 +4481,23 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         if (sqrt(rr) <= tol * sqrt(bb)) break;
     }
     c->p_iters_hint = converged_at > 0 ? converged_at : it;
-    if (fused && it > 0) {
+    if (xsum && it > 0) {
+        const XsumArgs xa = ring_args(it);
+        if (c->p_ns_active) {
+            if (c->pin_i >= 0)
+                hipLaunchKernelGGL(k_ns_shift_sum, dim3(1), dim3(64), 0, st, g, c->pin_i, c->pin_j, c->pin_value, S, (it - 1) & 1, xa, ahist,
+                                   x, c->scal + 81);
+            else
+                CFD_HIP(hipMemsetAsync(c->scal + 81, 0, sizeof(double), st));
+            CFD_HIP(hipGetLastError());
+            CFD_TRY(all_reduce(c, c->scal + 81, 1, 0));
+        }
+        c->probe_begin(12);
+        hipLaunchKernelGGL(k_cg_xsum, grid, blk, 0, st, g, T, S, (it - 1) & 1, xa, ahist,
+                           c->p_ns_active ? c->scal + 81 : (const double *)nullptr, x);
+        c->probe_end(12, 8.0 * (xa.n + 1 + xa.from_x));
+        CFD_HIP(hipGetLastError());
+    } else if (fused && it > 0) {
         if (c->p_ns_active) CFD_TRY(ns_shift_scalar(c, S, (it - 1) & 1, 1, it == 1, p, x));
         c->probe_begin(12);
         hipLaunchKernelGGL(k_cg_xlast, grid, blk, 0, st, g, T, S, (it - 1) & 1, it == 1, p,

@@ -691,6 +691,31 @@ def test_speculative_inner_iterations():
         assert rel_l2(mask_corners(a), mask_corners(b)) <= 1e-7
 
 
+@pytest.mark.parametrize("n,p_tol,spec", [(256, 1e-8, 1), (256, 1e-13, 0), (192, 1e-13, 1)])
+def test_pcg_solution_summed_from_the_kept_directions(n, p_tol, spec):
+    """Option `pcg_xsum` (default on): the fused MG-PCG direction step leaves x alone, the directions of the solve stay in
+    a ring of six planes and x = sum alpha_k p_k is summed once at the end in the order of the stepwise updates -- the
+    same bits as x += alpha p in every step.  The tight tolerance takes more than six iterations per solve (the ring is
+    emptied into x on the way), 192^2 has an odd multigrid level and a nullspace shift folded into the last sum."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for xs in (1, 0):
+        dev, ctl, cfg = bench.setup_device(n, False, 2, 1e-8, 0, tuning={"pcg_xsum": xs, "speculate": spec})
+        dev.set_solver(1e-8, 200, p_tol, 200, 1e-8, 200, True)
+        for step in range(4):
+            advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        out[xs] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P, L.F_PCORR)], dev.stats(), dev.kernel_counts())
+        dev.close()
+    (f1, st1, k1), (f0, st0, k0) = out[1], out[0]
+    assert k1["cg_pq"] == k0["cg_pq"] > 0 and st1["p_iters"] == st0["p_iters"]
+    assert (st1["p_iters"] > 6) == (p_tol < 1e-10), st1["p_iters"]
+    for a, b in zip(f1, f0):
+        assert np.array_equal(mask_corners(a), mask_corners(b)), np.abs(a - b).max()
+
+
 def _pcg_tail_pair(builder, fixup, tmp_path, extra=None):
     """The same case with the pressure solve as one launch (k_pcg_tail, default on small meshes) and as the launch-per-phase loop."""
     from cfd_amd import mesh as hip_mesh
