@@ -502,6 +502,7 @@ int cfd_upload_mesh(cfd_ctx *ctx, const double *cell_volume, const double *w_rig
     CFD_TRY(to_device(c, tmp.data(), c->m_lmin, CFD_KIND_CELL));
     c->mesh_set = true;
     c->mesh_halo2 = false;
+    c->rn_state = -1;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -526,6 +527,7 @@ int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node) {
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
     c->mesh_halo2 = false;
+    c->rn_state = -1;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -551,6 +553,7 @@ int cfd_mesh_from_rect(cfd_ctx *ctx, const double *x_nodes, const double *y_node
     CFD_HIP(hipStreamSynchronize(c->stream));
     c->mesh_set = true;
     c->mesh_halo2 = false;
+    c->rn_state = -1;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -676,6 +679,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "pcg_tail_cells") { if (iv < 0 || iv > TAIL_MAX_CELLS) { set_error("pcg_tail_cells: 0 .. %d", TAIL_MAX_CELLS); return CFD_E_ARG; } c->pcg_tail_cells = iv; c->p_built = false; }
     else if (n == "speculate") c->speculate = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "pcg_xsum") c->pcg_xsum = iv ? 1 : 0;
+    else if (n == "rect_normals") c->rn_opt = iv ? 1 : 0;
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "wide_mask") { if (iv < 0 || iv > 1023) { set_error("wide_mask: 0 .. 1023"); return CFD_E_ARG; } c->wide_mask = iv; }

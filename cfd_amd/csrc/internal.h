@@ -397,6 +397,7 @@ struct Ctx {
     bool bc_fresh = false;             // the ghosts of u, v, p [bc_cur] are those of k_flow_bc + exchange on the current values
     int bc_cur = -1, skip_fresh_bc = 1;
     bool mesh_halo2 = false;           // metric planes hold the neighbour slab's rows beyond the cuts (launch_correct_flux)
+    int rn_opt = 1, rn_state = -1;     // axis-aligned mesh (stencil.hip: rect_normals): option; -1 not looked at yet / 0 / 1
     int pcg_xsum = 1;                  // fused MG-PCG: x summed from the kept directions when the solve ends (k_cg_xsum) instead of updated every step
     int fuse_correct = 1;              // correction + boundary fill + closing flux pass in one marching kernel where correct_flux_ok()
     int per_i = 0, per_j = 0, wrap_p_i = 0, wrap_p_j = 0;
@@ -630,6 +631,7 @@ inline double global_cells(const Ctx *c) {
 }
 
 // linalg.hip
+bool rect_normals(Ctx *c);
 int sum_finish(Ctx *c, const double *partials, int nblocks, int nq, double *out);   // + all-reduce over slabs
 int reduce_finish(Ctx *c, int nq, int scal_off);       // partials -> scal[scal_off .. +nq)
 int read_scalars(Ctx *c, int off, int n, double *host);

@@ -517,6 +517,41 @@ struct FluxMarch {
     int wide = 4;        // 8: lockstep workgroups (blocks counts those)
 };
 constexpr int WIDE_FLUX = 128;       // Ctx::wide_mask bit of the flux kernels
+// Axis-aligned mesh?  Counts the faces whose area vector is not (S, 0) (i-faces) / (0, S) (j-faces) bit for bit: west and
+// south face of every cell, face ni of the last column, face nj of the last row of the mesh (not of a slab cut: that row
+// is the neighbour's).  Zero on every rank -> the marching flux kernels take n_ix = S_i, n_jy = S_j, n_iy = n_jx = 0 from
+// the area planes (template argument RN) and leave the four normal planes alone.
+__global__ void k_rect_normals(Geo g, MeshDev m, double *partials, int tiles_x, int tiles) {
+    double a = 0.0;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int i = (tile % tiles_x) * 64 + threadIdx.x, j = (tile / tiles_x) * 4 + threadIdx.y;
+        if (i >= g.ni || j >= g.nj) continue;
+        const size_t c = g.cell(i, j);
+        int bad = (m.nix[c] != m.si[c]) | (m.niy[c] != 0.0) | (m.njx[c] != 0.0) | (m.njy[c] != m.sj[c]);
+        if (i == g.ni - 1) bad |= (m.nix[c + 1] != m.si[c + 1]) | (m.niy[c + 1] != 0.0);
+        if (j == g.nj - 1 && !g.cuthi) bad |= (m.njx[c + g.pitch] != 0.0) | (m.njy[c + g.pitch] != m.sj[c + g.pitch]);
+        a += bad ? 1.0 : 0.0;
+    }
+    a = block_sum_256(a);
+    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = a;
+}
+// evaluated once per mesh, at the first marching flux pass (every rank gets there at the same point of the run: the sum
+// is all-reduced over the slabs); option rect_normals = 0 keeps the general kernels
+bool rect_normals(Ctx *c) {
+    if (!c->rn_opt) return false;
+    if (c->rn_state < 0) {
+        int tx;
+        const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
+        hipLaunchKernelGGL(k_rect_normals, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), c->partials, tx, tiles);
+        double bad = 1.0;
+        if (hipGetLastError() != hipSuccess || sum_finish(c, c->partials, nb, 1, c->scal + 54) != CFD_OK ||
+            read_scalars(c, 54, 1, &bad) != CFD_OK)
+            bad = 1.0;
+        c->rn_state = bad == 0.0 ? 1 : 0;
+    }
+    return c->rn_state == 1;
+}
+
 // lockstep form for the momentum / pressure right-hand-side passes on meshes with enough strips
 static inline void flux_march_widen(const Ctx *c, FluxMarch &m) {
     if (!(c->wide_mask & WIDE_FLUX) || m.nstrips < 16) return;
@@ -562,10 +597,19 @@ struct MomArgs {
     int nts;                       // nontemporal stores of the right-hand side planes (store_stream)
 };
 
+// RN (axis-aligned meshes, Ctx::rect_normals): every face's area vector is (S, 0) on the i-faces and (0, S) on the
+// j-faces, bit for bit (checked on the device once per mesh, rect_normals()), so the four normal planes are not read:
+// n_ix = S_i and n_jy = S_j come from the area planes the pass reads anyway, n_iy = n_jx = 0 (-32 B per cell; x * n_ix +
+// y * (+-0) is x * S_i to the bit wherever it is not zero itself).
+#define FX_NIX(R) (RN ? (R).si : (R).nix)
+#define FX_NIY(R) (RN ? 0.0 : (R).niy)
+#define FX_NJX(R) (RN ? 0.0 : (R).njx)
+#define FX_NJY(R) (RN ? (R).sj : (R).njy)
 // WPB = 8: lockstep workgroups of eight neighbouring strips (MarchItems, internal.h)
-template <int MODE, bool KG, bool DT = false, int WPB = 4>
+template <int MODE, bool KG, bool DT = false, int WPB = 4, bool RNA = false>
 __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxIn f, FluxMarch fm, MomArgs ma, double *bout,
                                                          double *partials) {
+    constexpr bool RN = RNA && MODE != 3;         // (the time-step pass reads no area planes)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const size_t P = g.pitch;
     const int rc = MODE == 3 ? 0 : f.rc;
@@ -585,8 +629,9 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
         auto fetch = [&](int j, FluxRow &R) {
             const size_t c = (size_t)(j + NG) * P + colo;
             R.u = f.u[c]; R.v = f.v[c];
-            R.wri = m.wri[c]; R.nix = m.nix[c]; R.niy = m.niy[c];
-            R.wnj = m.wnj[c]; R.njx = m.njx[c]; R.njy = m.njy[c];
+            R.wri = m.wri[c]; R.wnj = m.wnj[c];
+            if (RN) { R.nix = 0.0; R.niy = 0.0; R.njx = 0.0; R.njy = 0.0; }
+            else { R.nix = m.nix[c]; R.niy = m.niy[c]; R.njx = m.njx[c]; R.njy = m.njy[c]; }
             R.vol = m.vol[c];
             if (MODE == 3) {
                 R.p = 0.0; R.ap = 1.0; R.si = 0.0; R.sj = 0.0; R.k = 0.0;
@@ -622,7 +667,7 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                 const double wr = cur.wri, wl = 1.0 - wr;
                 const double ui = wl * uL + wr * cur.u;
                 const double vi = wl * vL + wr * cur.v;
-                fw_c = ui * cur.nix + vi * cur.niy;
+                fw_c = ui * FX_NIX(cur) + vi * FX_NIY(cur);
                 lw_c = fw_c;
                 if (rc) {
                     const double apL = lane_left(cur.ap);
@@ -639,7 +684,7 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                 const double wn = cur.wnj, ws = 1.0 - wn;
                 const double uj = ws * prv.u + wn * cur.u;
                 const double vj = ws * prv.v + wn * cur.v;
-                fs_c = uj * cur.njx + vj * cur.njy;
+                fs_c = uj * FX_NJX(cur) + vj * FX_NJY(cur);
                 ls_c = fs_c;
                 if (rc) {
                     double af = lo ? cur.ap : (hi ? prv.ap : ws * prv.ap + wn * cur.ap);
@@ -657,7 +702,7 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                 const double uW = lane_left(prv.u), uE = lane_right(prv.u);
                 const double vW = lane_left(prv.v), vE = lane_right(prv.v);
                 const double pW = lane_left(prv.p), pE = lane_right(prv.p);
-                const double wriE = lane_right(prv.wri), nixE = lane_right(prv.nix), niyE = lane_right(prv.niy);
+                const double wriE = lane_right(prv.wri), nixE = lane_right(FX_NIX(prv)), niyE = RN ? 0.0 : lane_right(prv.niy);
                 const double kW = KG ? lane_left(prv.k) : 0.0, kE = KG ? lane_right(prv.k) : 0.0;
                 if (jo >= j0 && out) {
                     const double fw = fw_p, fe = fe_p, fs = fs_p, fn = fs_c;
@@ -687,8 +732,8 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                         const double pe = (1.0 - wriE) * pc + wriE * pE;
                         const double ps = (1.0 - prv.wnj) * p2 + prv.wnj * pc;
                         const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.p;
-                        gx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
-                        gy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        gx = (nixE * pe - FX_NIX(prv) * pw + FX_NJX(cur) * pn - FX_NJX(prv) * ps) / vol;
+                        gy = (niyE * pe - FX_NIY(prv) * pw + FX_NJY(cur) * pn - FX_NJY(prv) * ps) / vol;
                     }
                     if (KG) {
                         const double pc = prv.k;
@@ -696,8 +741,8 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                         const double pe = (1.0 - wriE) * pc + wriE * kE;
                         const double ps = (1.0 - prv.wnj) * k2 + prv.wnj * pc;
                         const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.k;
-                        const double kx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
-                        const double ky = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        const double kx = (nixE * pe - FX_NIX(prv) * pw + FX_NJX(cur) * pn - FX_NJX(prv) * ps) / vol;
+                        const double ky = (niyE * pe - FX_NIY(prv) * pw + FX_NJY(cur) * pn - FX_NJY(prv) * ps) / vol;
                         gx = gx + kx;
                         gy = gy + ky;
                     }
@@ -736,7 +781,7 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                 const double vW = lane_left(prv.v), vE = lane_right(prv.v);
                 const double kW = lane_left(prv.k), kE = lane_right(prv.k);
                 const double wW = lane_left(prv.w), wE = lane_right(prv.w);
-                const double wriE = lane_right(prv.wri), nixE = lane_right(prv.nix), niyE = lane_right(prv.niy);
+                const double wriE = lane_right(prv.wri), nixE = lane_right(FX_NIX(prv)), niyE = RN ? 0.0 : lane_right(prv.niy);
                 if (jo >= j0 && out) {
                     const double fw = fw_p, fe = fe_p, fs = fs_p, fn = fs_c;
                     const double vol = prv.vol;
@@ -763,8 +808,8 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                         const double pe = (1.0 - wriE) * pc + wriE * uE;
                         const double ps = (1.0 - prv.wnj) * u2 + prv.wnj * pc;
                         const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.u;
-                        ux = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
-                        uy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        ux = (nixE * pe - FX_NIX(prv) * pw + FX_NJX(cur) * pn - FX_NJX(prv) * ps) / vol;
+                        uy = (niyE * pe - FX_NIY(prv) * pw + FX_NJY(cur) * pn - FX_NJY(prv) * ps) / vol;
                     }
                     {
                         const double pc = prv.v;
@@ -772,8 +817,8 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                         const double pe = (1.0 - wriE) * pc + wriE * vE;
                         const double ps = (1.0 - prv.wnj) * v2 + prv.wnj * pc;
                         const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.v;
-                        vx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
-                        vy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        vx = (nixE * pe - FX_NIX(prv) * pw + FX_NJX(cur) * pn - FX_NJX(prv) * ps) / vol;
+                        vy = (niyE * pe - FX_NIY(prv) * pw + FX_NJY(cur) * pn - FX_NJY(prv) * ps) / vol;
                     }
                     const double s2 = 2.0 * (ux * ux) + 2.0 * (vy * vy) + (uy + vx) * (uy + vx);
                     const double ks = fmax(prv.k, K_FLOOR), os = fmax(prv.w, OMEGA_FLOOR);
@@ -900,7 +945,9 @@ __device__ __forceinline__ void bc_ghost(const FlowBCSide &s, int t, double ui, 
     p = s.pa[t] * pi + s.pb[t];
 }
 
-template <bool KG, bool DT, int WPB, bool LOCK = (WPB > 4)>
+// RN: see k_flux_march.  The area S_j of a row's south face then travels with the early part of the row (CorrE, in place
+// of n_jy), so that the correction of row r still waits for no load of row r + 1's late part.
+template <bool KG, bool DT, int WPB, bool LOCK = (WPB > 4), bool RN = false>
 __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, CorrIn ci, FlowBCDev bc, FluxMarch fm, MomArgs ma,
                                                            double *partials) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -933,7 +980,9 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             const int rr = r < rlo ? rlo : (r > rhi ? rhi : r);
             const size_t c = (size_t)(rr + NG) * P + colw;
             R.pc = ci.pc[(size_t)(rr + NG) * P + colp];
-            R.wnj = m.wnj[c]; R.njx = m.njx[c]; R.njy = m.njy[c];
+            R.wnj = m.wnj[c];
+            if (RN) { R.njx = 0.0; R.njy = m.sj[c]; }          // (S_j in the slot of n_jy)
+            else { R.njx = m.njx[c]; R.njy = m.njy[c]; }
         };
         auto kload = [&](int rr) -> double {
             return KG ? (2.0 / 3.0) * ma.kgrad[(size_t)(rr + NG) * P + (size_t)((iraw < g.ni ? (iraw < -1 ? -1 : iraw) : g.ni) + CO)] : 0.0;
@@ -943,12 +992,15 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             const size_t c = (size_t)(rr + NG) * P + colw;
             R.us = ci.us[c]; R.vs = ci.vs[c]; R.u0 = ci.u0[c]; R.v0 = ci.v0[c]; R.p0 = ci.p0[c];
             R.ap = ci.ap[c]; R.vol = m.vol[c];
-            R.wri = m.wri[c]; R.nix = m.nix[c]; R.niy = m.niy[c]; R.si = m.si[c]; R.sj = m.sj[c];
+            R.wri = m.wri[c]; R.si = m.si[c];
+            if (RN) { R.nix = 0.0; R.niy = 0.0; R.sj = 0.0; }
+            else { R.nix = m.nix[c]; R.niy = m.niy[c]; R.sj = m.sj[c]; }
             R.k = kload(rr);
             R.lmin = (DT && ma.use_diff) ? m.lmin[c] : 1.0;
             if (ihi) {       // the west face of this lane is face ni, whose entries are separate from face 0's
                 const size_t ce = (size_t)(rr + NG) * P + (size_t)(g.ni + CO);
-                R.wri = m.wri[ce]; R.nix = m.nix[ce]; R.niy = m.niy[ce]; R.si = m.si[ce];
+                R.wri = m.wri[ce]; R.si = m.si[ce];
+                if (!RN) { R.nix = m.nix[ce]; R.niy = m.niy[ce]; }
             }
         };
         // raw window around row r: pcA = p' of row r - 1; Eb, Ec, Ed = E of rows r, r + 1, r + 2 (Ed in flight);
@@ -960,19 +1012,22 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             const double pcc = Eb.pc;
             const double pW = lane_left(pcc), pE = lane_right(pcc);
             // east face of the cell = west face of the right lane (lane ihi holds face ni, the east face of cell ni - 1)
-            const double wriE = lane_right(Lb.wri), nixE = lane_right(Lb.nix), niyE = lane_right(Lb.niy);
+            const double wriE = lane_right(Lb.wri), nixE = lane_right(RN ? Lb.si : Lb.nix), niyE = RN ? 0.0 : lane_right(Lb.niy);
             // lane ihi itself is a ghost (non-periodic, value replaced below) or the wrapped cell 0, whose own west face
             // is face 0
-            double wri = Lb.wri, nix = Lb.nix, niy = Lb.niy;
+            double wri = Lb.wri, nix = RN ? Lb.si : Lb.nix, niy = RN ? 0.0 : Lb.niy;
             if (ihi && ci.per_i) {
                 const size_t c0 = (size_t)(r + NG) * P + colw;
-                wri = m.wri[c0]; nix = m.nix[c0]; niy = m.niy[c0];
+                wri = m.wri[c0];
+                if (RN) nix = m.si[c0];
+                else { nix = m.nix[c0]; niy = m.niy[c0]; }
             }
             const double pw = (1.0 - wri) * pW + wri * pcc;
             const double pe = (1.0 - wriE) * pcc + wriE * pE;
             const double ps = (1.0 - Eb.wnj) * pcA + Eb.wnj * pcc;
             const double pn = (1.0 - Ec.wnj) * pcc + Ec.wnj * Ec.pc;
             const double vol = Lb.vol;
+            // (RN: E.njx = 0 and E.njy = S_j as loaded)
             const double gx = (nixE * pe - nix * pw + Ec.njx * pn - Eb.njx * ps) / vol;
             const double gy = (niyE * pe - niy * pw + Ec.njy * pn - Eb.njy * ps) / vol;
             const double d = vol / Lb.ap;
@@ -995,7 +1050,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             if (ghi) bc_ghost(bc.side[CFD_SIDE_IMAX], tr, uL, vL, pL, un, vn, pn2);
             R.u = un; R.v = vn; R.p = pn2; R.ap = rc ? Lb.ap : 1.0;
             R.wri = Lb.wri; R.nix = Lb.nix; R.niy = Lb.niy; R.si = Lb.si;
-            R.wnj = Eb.wnj; R.njx = Eb.njx; R.njy = Eb.njy; R.sj = Lb.sj;
+            R.wnj = Eb.wnj; R.njx = Eb.njx; R.njy = Eb.njy; R.sj = RN ? Eb.njy : Lb.sj;
             R.vol = Lb.vol; R.k = Lb.k; R.lmin = Lb.lmin;
         };
         // first row this segment needs corrected
@@ -1039,7 +1094,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             } else {
                 // ghost row nj from the corrected row nj - 1 (= prv); its south-face entries and k are row nj's
                 bc_ghost(bc.side[CFD_SIDE_JMAX], cw, prv.u, prv.v, prv.p, cur.u, cur.v, cur.p);
-                cur.wnj = Ec.wnj; cur.njx = Ec.njx; cur.njy = Ec.njy; cur.sj = Lc.sj; cur.k = Lc.k;
+                cur.wnj = Ec.wnj; cur.njx = Ec.njx; cur.njy = Ec.njy; cur.sj = RN ? Ec.njy : Lc.sj; cur.k = Lc.k;
             }
             // ---- from here on: the MODE 2 body of k_flux_march, same expressions
             const double uL = lane_left(cur.u), vL = lane_left(cur.v), pL = lane_left(cur.p);
@@ -1048,7 +1103,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
                 const double wr = cur.wri, wl = 1.0 - wr;
                 const double ui = wl * uL + wr * cur.u;
                 const double vi = wl * vL + wr * cur.v;
-                fw_c = ui * cur.nix + vi * cur.niy;
+                fw_c = ui * FX_NIX(cur) + vi * FX_NIY(cur);
                 lw_c = fw_c;
                 if (rc) {
                     const double apL = lane_left(cur.ap);
@@ -1064,7 +1119,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
                 const double wn = cur.wnj, ws = 1.0 - wn;
                 const double uj = ws * prv.u + wn * cur.u;
                 const double vj = ws * prv.v + wn * cur.v;
-                fs_c = uj * cur.njx + vj * cur.njy;
+                fs_c = uj * FX_NJX(cur) + vj * FX_NJY(cur);
                 ls_c = fs_c;
                 if (rc) {
                     double af = lo ? cur.ap : (hi ? prv.ap : ws * prv.ap + wn * cur.ap);
@@ -1080,7 +1135,7 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
                 const double uW = lane_left(prv.u), uE = lane_right(prv.u);
                 const double vW = lane_left(prv.v), vE = lane_right(prv.v);
                 const double pW = lane_left(prv.p), pE = lane_right(prv.p);
-                const double wriE = lane_right(prv.wri), nixE = lane_right(prv.nix), niyE = lane_right(prv.niy);
+                const double wriE = lane_right(prv.wri), nixE = lane_right(FX_NIX(prv)), niyE = RN ? 0.0 : lane_right(prv.niy);
                 const double kW = KG ? lane_left(prv.k) : 0.0, kE = KG ? lane_right(prv.k) : 0.0;
                 if (jo >= j0 && out) {
                     const double fw = fw_p, fe = fe_p, fs = fs_p, fn = fs_c;
@@ -1108,8 +1163,8 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
                         const double pe = (1.0 - wriE) * pc + wriE * pE;
                         const double ps = (1.0 - prv.wnj) * p2 + prv.wnj * pc;
                         const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.p;
-                        gx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
-                        gy = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        gx = (nixE * pe - FX_NIX(prv) * pw + FX_NJX(cur) * pn - FX_NJX(prv) * ps) / vol;
+                        gy = (niyE * pe - FX_NIY(prv) * pw + FX_NJY(cur) * pn - FX_NJY(prv) * ps) / vol;
                     }
                     if (KG) {
                         const double pc = prv.k;
@@ -1117,8 +1172,8 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
                         const double pe = (1.0 - wriE) * pc + wriE * kE;
                         const double ps = (1.0 - prv.wnj) * k2 + prv.wnj * pc;
                         const double pn = (1.0 - cur.wnj) * pc + cur.wnj * cur.k;
-                        const double kx = (nixE * pe - prv.nix * pw + cur.njx * pn - prv.njx * ps) / vol;
-                        const double ky = (niyE * pe - prv.niy * pw + cur.njy * pn - prv.njy * ps) / vol;
+                        const double kx = (nixE * pe - FX_NIX(prv) * pw + FX_NJX(cur) * pn - FX_NJX(prv) * ps) / vol;
+                        const double ky = (niyE * pe - FX_NIY(prv) * pw + FX_NJY(cur) * pn - FX_NJY(prv) * ps) / vol;
                         gx = gx + kx;
                         gy = gy + ky;
                     }
@@ -1325,13 +1380,18 @@ int launch_correct_flux(Ctx *c, double dt, double ru, double rv, double rp, bool
     c->kc[KC_CORRECT_FLUX] += 1;
     const bool dt_too = c->dt_lookahead && c->dtp_set && (c->dtp_use_cfl || !c->turbulent);
     // u*, v*, u0, v0, p0, p', a_P, V, w x 2, n x 4, S x 2 read; u, v, p, b_u, b_v written (+ k, + lmin)
-    c->last_rhs_bytes = 176.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0);
+    // (axis-aligned mesh: the four normal planes are not read)
+    const bool rn = rect_normals(c);
+    c->last_rhs_bytes = 176.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0);
     if (dt_too) {
         ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
         ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
 #define LAUNCH_CF(KGv, DTv)                                                                                                   \
     do {                                                                                                                     \
-        if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+        if (rn) {                                                                                                            \
+            if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+            else LAUNCH_FLUX(fm, (k_correct_flux<KGv, DTv, 4, false, true>), (k_correct_flux<KGv, DTv, 8, true, true>), c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+        } else if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
         else LAUNCH_FLUX(fm, (k_correct_flux<KGv, DTv, 4>), (k_correct_flux<KGv, DTv, 8>), c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials);                       \
     } while (0)
         if (c->turbulent) LAUNCH_CF(true, true);
@@ -1420,29 +1480,30 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         const bool dt_too = cont && c->dt_lookahead && c->dtp_set && (c->dtp_use_cfl || !c->turbulent);
         // 13 planes read (u, v, p, a_P, V, w x 2, n x 4, S x 2), b_u, b_v written; + k in turbulent runs; + lmin for the
         // diffusive minimum taken ahead
-        c->last_rhs_bytes = 120.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0);
+        const bool rn = rect_normals(c);
+        c->last_rhs_bytes = 120.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0);
+#define LAUNCH_FM2(KGv, DTv)                                                                                                  \
+    do {                                                                                                                     \
+        if (rn) LAUNCH_FLUX(fm, (k_flux_march<2, KGv, DTv, 4, true>), (k_flux_march<2, KGv, DTv, 8, true>), c->g, c->mesh(), f, fm, ma, (double *)nullptr, c->partials); \
+        else LAUNCH_FLUX(fm, (k_flux_march<2, KGv, DTv>), (k_flux_march<2, KGv, DTv, 8>), c->g, c->mesh(), f, fm, ma, (double *)nullptr, c->partials); \
+    } while (0)
         if (dt_too) {
             // turbulent runs: nu_t changes before the next step, only the advective minimum can be taken ahead
             ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
             ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
-            if (c->turbulent)
-                LAUNCH_FLUX(fm, (k_flux_march<2, true, true>), (k_flux_march<2, true, true, 8>), c->g, c->mesh(), f, fm, ma,
-                            (double *)nullptr, c->partials);
-            else
-                LAUNCH_FLUX(fm, (k_flux_march<2, false, true>), (k_flux_march<2, false, true, 8>), c->g, c->mesh(), f, fm, ma,
-                            (double *)nullptr, c->partials);
+            if (c->turbulent) LAUNCH_FM2(true, true);
+            else LAUNCH_FM2(false, true);
             hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials + MAX_PARTIALS, fm.blocks, 2,
                                c->scal + DT_AHEAD_OFF);
             c->dt_ahead = true;
             c->dt_ahead_diff = !c->turbulent;
             c->dt_ahead_cur = c->cur;
         } else if (c->turbulent) {
-            LAUNCH_FLUX(fm, (k_flux_march<2, true>), (k_flux_march<2, true, false, 8>), c->g, c->mesh(), f, fm, ma,
-                        (double *)nullptr, c->partials);
+            LAUNCH_FM2(true, false);
         } else {
-            LAUNCH_FLUX(fm, (k_flux_march<2, false>), (k_flux_march<2, false, false, 8>), c->g, c->mesh(), f, fm, ma,
-                        (double *)nullptr, c->partials);
+            LAUNCH_FM2(false, false);
         }
+#undef LAUNCH_FM2
         CFD_HIP(hipGetLastError());
         if (cont) return finish_continuity(c, fm.blocks, cont, dt_too);
         return CFD_OK;
@@ -1544,8 +1605,12 @@ int launch_turb_rhs(Ctx *c, double dt) {
         MomArgs ma{c->k, c->ti, c->tj, 1.0 / dt, 0.0, 0.0, c->per_i, c->per_j, c->bu, c->bv};
         ma.nts = c->nts();
         ma.nut = c->nut; ma.omega = c->omega;
-        LAUNCH_FLUX(fm, (k_flux_march<4, false>), (k_flux_march<4, false, false, 8>), c->g, c->mesh(), f, fm, ma,
-                    (double *)nullptr, c->partials);
+        if (rect_normals(c))
+            LAUNCH_FLUX(fm, (k_flux_march<4, false, false, 4, true>), (k_flux_march<4, false, false, 8, true>), c->g, c->mesh(), f, fm, ma,
+                        (double *)nullptr, c->partials);
+        else
+            LAUNCH_FLUX(fm, (k_flux_march<4, false>), (k_flux_march<4, false, false, 8>), c->g, c->mesh(), f, fm, ma,
+                        (double *)nullptr, c->partials);
         CFD_HIP(hipGetLastError());
         return CFD_OK;
     }
@@ -1619,9 +1684,11 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
         ma.nts = c->nts();
         c->kc[KC_FLUX_MARCH] += 1;
         if (fm.nstrips > 1) c->kc[KC_FLUX_MARCH_MULTISTRIP] += 1;
+        const bool rn = rect_normals(c);
         c->probe_begin(13);
-        LAUNCH_FLUX(fm, (k_flux_march<1, false>), (k_flux_march<1, false, false, 8>), c->g, c->mesh(), f, fm, ma, b, c->partials);
-        c->probe_end(13, 112.0);       // u, v, p, a_P, V, w x 2, n x 4, S x 2 read, b written
+        if (rn) LAUNCH_FLUX(fm, (k_flux_march<1, false, false, 4, true>), (k_flux_march<1, false, false, 8, true>), c->g, c->mesh(), f, fm, ma, b, c->partials);
+        else LAUNCH_FLUX(fm, (k_flux_march<1, false>), (k_flux_march<1, false, false, 8>), c->g, c->mesh(), f, fm, ma, b, c->partials);
+        c->probe_end(13, rn ? 80.0 : 112.0);       // u, v, p, a_P, V, w x 2, n x 4 (not on axis-aligned meshes), S x 2 read, b written
     } else {
         hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
     }
