@@ -197,13 +197,16 @@ def cpu_baseline(n_cpu, steps, max_iter):
 
 
 KERNEL_NAMES = {
-    0: "pressure PCG direction step: p update + SpMV + (p,q) + deferred x update (k_cg_pq)",
+    0: "pressure PCG direction step: p update + SpMV + (p,q) (k_cg_pq; x is summed from the kept directions when the solve "
+       "ends, k_cg_xsum)",
     1: "MG pre-smoother, finest level: 3 fused Jacobi sweeps + residual + restrict (k_mg_down_k<true,3>)",
     2: "velocity / pressure correction + ghost cells + momentum RHS + continuity sum (+ next step's time-step minima in "
-       "laminar runs, + grad(2/3 k) in k-omega runs) in one marching pass (k_correct_flux, 176-184 B/cell; the first "
-       "iteration of a run and contexts the fused pass does not cover run the Rhie-Chow kernel k_flux_march<2>, 120-128 B/cell)",
+       "laminar runs, + grad(2/3 k) in k-omega runs) in one marching pass (k_correct_flux, 176-184 B/cell, 32 B less on "
+       "axis-aligned meshes, whose normal planes are not read; the first iteration of a run and contexts the fused pass does "
+       "not cover run the Rhie-Chow kernel k_flux_march<2>, 120-128 B/cell)",
     8: "momentum Chebyshev, four fused iterations of u and v per launch (k_chebk<2,4>)",
-    9: "momentum Chebyshev, four fused iterations of one right-hand side per launch (k_chebk<1,4>)",
+    9: "momentum Chebyshev, four or six fused iterations of one right-hand side per launch (k_chebk<1,4> / k_chebk<1,6>: "
+       "the same 64 B per cell buy six iterations where that saves a launch, at 12 instead of 8 halo lanes per wave)",
     10: "MG pre-smoother with the PCG residual update folded in (k_mg_down_k<true,3,true>)",
     7: "MG post-smoother, finest level: prolong + 3 fused Jacobi sweeps + (r,z) (k_mg_up_k<true,3>)"}
 CANDIDATES = (0, 8, 9, 7, 1, 10, 2)
@@ -211,8 +214,8 @@ CANDIDATES = (0, 8, 9, 7, 1, 10, 2)
 # split is reported beside it): k_cg_pq's three forms already share id 0
 GROUPS = {"k_chebk": (8, 9), "k_cg_pq": (0,), "k_mg_up_k": (7,), "k_mg_down_k": (1, 10), "k_correct_flux": (2,)}
 GROUP_NAMES = {
-    "k_chebk": "momentum Chebyshev, four fused iterations per launch (k_chebk<2,4> on u and v, k_chebk<1,4> once one of "
-               "them has converged)",
+    "k_chebk": "momentum Chebyshev, four fused iterations per launch (k_chebk<2,4> on u and v; k_chebk<1,4> / <1,6> once "
+               "one of them has converged)",
     "k_cg_pq": KERNEL_NAMES[0],
     "k_mg_up_k": KERNEL_NAMES[7],
     "k_mg_down_k": "MG pre-smoother, finest level: 3 fused Jacobi sweeps + residual + restrict, with / without the PCG "

@@ -368,6 +368,7 @@ struct Ctx {
         int nb = 0, K = 0;
         double tol = 0.0;
         int retire_k[2] = {0, 0};      // iterate each right-hand side was taken from
+        unsigned char kseq[12] = {};   // iterations fused by each launch of that solve (4, or 6: chebyshev_fused)
     } cheb_plan;
     static constexpr int SPEC_MAX_LAUNCHES = 12;
     struct SpecCheb {
@@ -375,6 +376,7 @@ struct Ctx {
         int nb = 0, K = 0, launches = 0;
         double tol = 0.0;
         int na[SPEC_MAX_LAUNCHES] = {};            // right-hand sides in launch m (0-based)
+        int k0[SPEC_MAX_LAUNCHES] = {}, kl[SPEC_MAX_LAUNCHES] = {};     // first and last iterate whose residual launch m summed
         int t[SPEC_MAX_LAUNCHES][2] = {};          // position of right-hand side q among them, -1: not in the launch
         int k[2] = {0, 0};                         // iterate each right-hand side was taken from
     } spec_cheb;
@@ -397,6 +399,7 @@ struct Ctx {
     bool bc_fresh = false;             // the ghosts of u, v, p [bc_cur] are those of k_flow_bc + exchange on the current values
     int bc_cur = -1, skip_fresh_bc = 1;
     bool mesh_halo2 = false;           // metric planes hold the neighbour slab's rows beyond the cuts (launch_correct_flux)
+    int cheb_k6 = 1;                   // Chebyshev launches with one right-hand side left fuse six iterations (single rank, lockstep form)
     int rn_opt = 1, rn_state = -1;     // axis-aligned mesh (stencil.hip: rect_normals): option; -1 not looked at yet / 0 / 1
     int pcg_xsum = 1;                  // fused MG-PCG: x summed from the kept directions when the solve ends (k_cg_xsum) instead of updated every step
     int fuse_correct = 1;              // correction + boundary fill + closing flux pass in one marching kernel where correct_flux_ok()

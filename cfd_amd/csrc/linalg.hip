@@ -2746,6 +2746,14 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         mgeo.nsegs = (g.nj + Ls - 1) / Ls;
         mgeo.xcd = c->xcd_map;
     }
+    // Six fused iterations for the launches that carry ONE right-hand side (option cheb_k6, default on; single rank: a cut
+    // holds four halo rows): the one-right-hand-side form of K = 4 runs one workgroup of eight waves per CU at 154 registers,
+    // and so does K = 6 below 256 -- the same 64 B per cell buy six iterations for 12 instead of 8 halo lanes
+    // (v of the bench channel: 8 + 12 iterations in 2 + 2 launches instead of 2 + 3).  The stages are the same expressions
+    // on the same operands: every iterate has the bits of the K = 4 sequence.
+    constexpr int K6 = 6;
+    MarchGeo mgeo6 = mgeo;
+    mgeo6.nstrips = (g.ni + (64 - 2 * K6) - 1) / (64 - 2 * K6);
     // lockstep workgroups: per launch (one or two right-hand sides), see the loop
     const bool wide_ok = K == 4 && c->cheb_prefetch == 2;
     const int wide2 = wide_ok ? march_wide(c, mgeo, WIDE_CHEB2) : 4, wide1 = wide_ok ? march_wide(c, mgeo, WIDE_CHEB1) : 4;
@@ -2815,6 +2823,8 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         sc = Ctx::SpecCheb{};
         sc.used = true; sc.nb = NB; sc.K = K; sc.tol = tol;
     }
+    int k_next = 0;                    // iterate the next launch starts from
+    unsigned char kseq[Ctx::SPEC_MAX_LAUNCHES] = {};      // iterations fused by launch m of this solve
     for (int m = 1;; ++m) {
         int qs[2], na = 0;
         for (int q = 0; q < NB; ++q)
@@ -2829,17 +2839,38 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             if (na == 2) CFD_TRY(halo_exchange(c, g, K, cur_k[0], cur_k[1], cur_m[0], cur_m[1]));
             else CFD_TRY(halo_exchange(c, g, K, cur_k[qs[0]], cur_m[qs[0]]));
         }
-        ChebStages<K> cf;
-        for (int s2 = 0; s2 < K; ++s2) cc.next(cf.c1[s2], cf.c2[s2]);
         const int probe_id = (na == 2) ? 8 : 9;      // 8: both right-hand sides in the launch, 9: one
         const int wide_in = na == 2 ? wide2 : wide1;
+        // (the first launch of a solve keeps K: its sums are read one launch late as those of iterates 0 and K - 1)
+        const bool six_ok = K == 4 && c->cheb_k6 && m > 1 && na == 1 && NB == 2 && c->comm.nranks == 1 && wide_ok && wide_in == 8 &&
+                            !(mgeo.nstrips >= 16 && (c->wide_mask & 512) && (c->wide_mask & WIDE_CHEB1)) && mgeo6.nstrips >= 16;
+        // ... where that saves launches: a six-iteration launch costs about 1.2 four-iteration ones, so it pays when the
+        // iterate the bound predicts (kq) is reached in fewer launches of six than of four, decided launch by launch (12
+        // iterations to go: 6 + 6; 10: 6 + 4; 8: 4 + 4).  A replay repeats the sequence of the solve it replays, so that
+        // it sums the residuals of the same iterates (Ctx::ChebPlan::kseq).
+        bool six = false;
+        if (six_ok && spec) {
+            six = m <= Ctx::SPEC_MAX_LAUNCHES && plan.kseq[m - 1] == K6;
+        } else if (six_ok) {
+            const int rem = kq[qs[0]] - k_next + 1;
+            const int n4 = (rem + K - 1) / K, n6 = (rem + K6 - 1) / K6;
+            six = rem > 0 && 6 * n6 < 5 * n4;
+        }
+        const int Km = six ? K6 : K;
+        if (m <= Ctx::SPEC_MAX_LAUNCHES) kseq[m - 1] = (unsigned char)Km;
+        const int k0m = k_next;
+        k_next += Km;
+        ChebStages<K> cf;
+        ChebStages<K6> cf6;
+        if (six) for (int s2 = 0; s2 < K6; ++s2) cc.next(cf6.c1[s2], cf6.c2[s2]);
+        else for (int s2 = 0; s2 < K; ++s2) cc.next(cf.c1[s2], cf.c2[s2]);
         // lockstep workgroups of four strips: the two-right-hand-side form (two waves per SIMD) and, bit 512, the
         // one-right-hand-side form (154 registers = three waves per SIMD: one workgroup of eight leaves a third of the
         // CU's wave slots empty, three workgroups of four fill them)
         const bool lock4 = wide_ok && mgeo.nstrips >= 16 &&
                            ((wide_in == 4 && na == 2 && NB == 2 && (c->wide_mask & 256)) || (na == 1 && (c->wide_mask & 512) && (c->wide_mask & WIDE_CHEB1)));
         const int wide = lock4 ? 4 : wide_in;
-        const dim3 grid(march_grid(mgeo, wide, lock4));
+        const dim3 grid(six ? march_grid(mgeo6, 8, false) : march_grid(mgeo, wide, lock4));
         c->probe_begin(probe_id);
         if (na == NB) {
             CVecs<NB> xk, xm;
@@ -2867,7 +2898,9 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             const int q = qs[0];
             CVecs<1> b1{{b[q]}}, xk{{cur_k[q]}}, xm{{cur_m[q]}};
             Vecs<1> o1{{set[m & 1][0][q]}}, o2{{set[m & 1][1][q]}};
-            if (K == 2)
+            if (six)
+                hipLaunchKernelGGL((k_chebk<1, K6, 2, 8>), grid, dim3(512), 0, st, op, mgeo6, cf6, 0, c->nts(), b1, xk, xm, o1, o2, c->partials);
+            else if (K == 2)
                 hipLaunchKernelGGL((k_cheb2<1>), grid, dim3(256), 0, st, op, mgeo, cf.c1[0], cf.c2[0], cf.c1[1], cf.c2[1], 0, b1, xk,
                                    xm, o1, o2, c->partials);
             else if (wide == 8)
@@ -2884,7 +2917,7 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         c->probe_end(probe_id, 8.0 * (3 + (5 - (m == 1 ? 1 : 0)) * na));
         c->kc[K == 4 ? (na == 2 ? KC_CHEB4_2RHS : KC_CHEB4_1RHS) : KC_CHEB2] += 1;
         CFD_HIP(hipGetLastError());
-        int k0 = K * (m - 1);                      // this launch measured |r_k0| and |r_{k0+K-1}|
+        int k0 = k0m;                              // this launch measured |r_k0| and |r_{k0+Km-1}|
         if (spec) {
             // the sums of every launch go to slots of their own (this rank's part; one all-reduce over all of them when the
             // solve ends): the closing read sees the whole residual history and can move the schedule either way
@@ -2895,11 +2928,13 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
             CFD_HIP(hipGetLastError());
             sc.launches = m;
             sc.na[m - 1] = na;
+            sc.k0[m - 1] = k0m;
+            sc.kl[m - 1] = k0m + Km - 1;
             sc.t[m - 1][0] = sc.t[m - 1][1] = -1;
             for (int t = 0; t < na; ++t) sc.t[m - 1][qs[t]] = t;
             for (int t = 0; t < na; ++t) {
                 const int q = qs[t], kr = plan.retire_k[q];
-                if (kr != k0 && kr != k0 + K - 1) continue;
+                if (kr != k0 && kr != k0 + Km - 1) continue;
                 sc.k[q] = kr;
                 final_where[q] = kr == k0 ? cur_k[q] : set[m & 1][0][q];
                 act[q] = false;
@@ -2914,7 +2949,7 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                 return deliver(true);
             }
             bool overdue = false;                  // (a schedule whose points this launch sequence never visits: not replayable)
-            for (int q = 0; q < NB; ++q) overdue = overdue || (act[q] && plan.retire_k[q] < k0 + K);
+            for (int q = 0; q < NB; ++q) overdue = overdue || (act[q] && plan.retire_k[q] < k0 + Km);
             if (overdue) { set_error("Chebyshev replay: schedule point missed"); return CFD_E_STATE; }
             continue;
         }
@@ -2933,12 +2968,13 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         for (int pass = 0; pass < n_pass; ++pass) {
           const bool late_first = first_pending;         // pass 0 of two: the data of launch 1, read now
           const int mm = late_first ? 1 : m;
-          if (late_first) k0 = 0; else k0 = K * (m - 1);
+          const int Kp = late_first ? K : Km;            // iterations of the launch whose sums this pass looks at
+          if (late_first) k0 = 0; else k0 = k0m;
           if (!late_first) {
               kmin = 1 << 30;
               for (int t = 0; t < na; ++t) if (act[qs[t]]) kmin = std::min(kmin, kq[qs[t]]);
           }
-          if (late_first || mm == 1 || k0 + K - 1 >= kmin || k0 + K - 1 >= klimit) {
+          if (late_first || mm == 1 || k0 + Kp - 1 >= kmin || k0 + Kp - 1 >= klimit) {
             // partial sums of a launch with na right-hand sides: [t] = |r_k0|^2, [na + t] = |r_{k0+K-1}|^2, [2 na + t] = |b|^2
             const int nq = mm == 1 ? 3 * na : 2 * na;
             double got[6];
@@ -2975,7 +3011,7 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                 const int q = qs[t];
                 if (!act[q]) continue;               // retired by the late look at launch 1
                 if (conv(q, got[t])) CFD_TRY(retire(q, k0, got[t], it_k0[q]));
-                else if (conv(q, got[na + t])) CFD_TRY(retire(q, k0 + K - 1, got[na + t], it_last[q]));
+                else if (conv(q, got[na + t])) CFD_TRY(retire(q, k0 + Kp - 1, got[na + t], it_last[q]));
             }
             if (!act[0] && !act[NB - 1]) {
                 *iters = std::max(kdone[0], kdone[NB - 1]);
@@ -2985,18 +3021,19 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
                     c->cheb_plan.valid = true;
                     c->cheb_plan.D = op.D; c->cheb_plan.nb = NB; c->cheb_plan.K = K; c->cheb_plan.tol = tol;
                     c->cheb_plan.retire_k[0] = kdone[0]; c->cheb_plan.retire_k[1] = kdone[NB - 1];
+                    for (int l = 0; l < Ctx::SPEC_MAX_LAUNCHES; ++l) c->cheb_plan.kseq[l] = kseq[l];
                 }
                 return deliver(true);
             }
             if (late_first) continue;                // now the sums of launch 2 itself, if it is time for them
-            if (k0 + K - 1 >= klimit) {
+            if (k0 + Kp - 1 >= klimit) {
                 // bound not met (spectrum outside the interval): hand the newest iterate to BiCGStab
                 CFD_TRY(deliver(false));
                 for (int q = 0; q < NB; ++q)
                     if (act[q] && set[m & 1][1][q] != x[q])
                         CFD_HIP(hipMemcpyAsync(x[q], set[m & 1][1][q], g.plane_elems() * sizeof(double), hipMemcpyDeviceToDevice, st));
                 *used = 2;
-                *iters = k0 + K;
+                *iters = k0 + Kp;
                 return CFD_OK;
             }
           }
@@ -4544,9 +4581,9 @@ int spec_verify(Ctx *c, double *res, bool *ok) {
             for (int m = 1; m <= sc.launches; ++m) {
                 const int t = sc.t[m - 1][q];
                 if (t < 0) continue;
-                const int off = m == 1 ? SPEC_CHEB_OFF : SPEC_CHEB_OFF + 8 + 4 * (m - 2), na = sc.na[m - 1], k0 = sc.K * (m - 1);
+                const int off = m == 1 ? SPEC_CHEB_OFF : SPEC_CHEB_OFF + 8 + 4 * (m - 2), na = sc.na[m - 1];
                 const double at[2] = {h[off + t], h[off + na + t]};
-                const int kk[2] = {k0, k0 + sc.K - 1};
+                const int kk[2] = {sc.k0[m - 1], sc.kl[m - 1]};
                 for (int e = 0; e < 2; ++e) {
                     if (kk[e] == sc.k[q]) taken = at[e];
                     if (earliest < 0 && kk[e] < sc.k[q] && conv(at[e], SPEC_MARGIN)) earliest = kk[e];

@@ -750,6 +750,43 @@ def test_axis_aligned_meshes_leave_the_normal_planes_alone(kind):
         assert np.array_equal(mask_corners(a), mask_corners(b)), np.abs(a - b).max()
 
 
+@pytest.mark.parametrize("turbulent,spec", [(False, 1), (False, 0), (True, 1)])
+def test_six_fused_chebyshev_iterations_for_a_single_right_hand_side(turbulent, spec):
+    """Option `cheb_k6` (default on, single rank, lockstep form: meshes of >= 832 columns): once one of the two right-hand
+    sides of a Chebyshev solve has converged, the launches that carry the other one alone fuse six iterations instead of
+    four where that saves a launch (k_chebk<1, 6>: 12 halo lanes instead of 8 for the same 64 B per cell; 10 - 12
+    iterations to go: 6 + 4 / 6 + 6 instead of 4 + 4 + 4).  Same expressions on the same operands, so
+    every iterate has the bits of the four-iteration sequence; what may differ is the iterate a right-hand side is taken
+    from (residuals are summed at the first and last iterate of a launch): with the solves driven to 1e-12 the fields
+    agree to 1e-9, host-checked and replayed schedules alike, in fewer launches."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for k6 in (1, 0):
+        dev, ctl, cfg = bench.setup_device(2048, turbulent, 2, 1e-8, 0, tuning={"cheb_k6": k6, "speculate": spec})
+        dev.set_solver(1e-12, 200, 1e-12, 200, 1e-12, 200, True)
+        for step in range(5):
+            advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        names = (L.F_U, L.F_V, L.F_P) + ((L.F_K, L.F_OMEGA) if turbulent else ())
+        out[k6] = ([dev.download(f) for f in names], dev.stats(), dev.kernel_counts())
+        dev.close()
+    (f1, st1, k1), (f0, st0, k0) = out[1], out[0]
+    # (the two-right-hand-side launches may differ by a few: a right-hand side can leave one measured iterate earlier or later)
+    # (the k-omega run's solves leave few iterations for a single right-hand side: never more launches, fewer in the laminar runs)
+    assert k1["cheb4_2rhs"] > 0 and 0 < k1["cheb4_1rhs"] <= k0["cheb4_1rhs"], (k1, k0)
+    assert k1["cheb4_2rhs"] + k1["cheb4_1rhs"] <= k0["cheb4_2rhs"] + k0["cheb4_1rhs"], (k1, k0)
+    if not turbulent:
+        assert k1["cheb4_1rhs"] < k0["cheb4_1rhs"], (k1, k0)
+    assert abs(st1["mom_iters"] - st0["mom_iters"]) <= 2
+    assert k1["bicgstab_iters"] == k0["bicgstab_iters"] == 0 and st1["p_iters"] == st0["p_iters"]
+    if spec:
+        assert k1["speculative_iterations"] > 0 and k1["speculative_redone"] <= 1
+    for a, b in zip(f1, f0):
+        assert rel_l2(mask_corners(a), mask_corners(b)) <= 1e-9
+
+
 def _pcg_tail_pair(builder, fixup, tmp_path, extra=None):
     """The same case with the pressure solve as one launch (k_pcg_tail, default on small meshes) and as the launch-per-phase loop."""
     from cfd_amd import mesh as hip_mesh
