@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per cell and launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this command at
 # 8192^2 (tools/pmc_summary.py: FETCH_SIZE x 2 + WRITE_SIZE, fabric side, Infinity-Cache hits included)
 PMC_TRAFFIC_BYTES_PER_CELL_8192 = {}       # filled from the newest profiles/r*_pmc8192_bytes_per_cell.csv of the uniform laminar run
-PMC_KERNEL_OF_PROBE = {0: "k_cg_pq", 8: "k_chebk<2,4", 9: "k_chebk<1,4", 7: "k_mg_up_k<true", 1: "k_mg_down_k<true,3,false",
+PMC_KERNEL_OF_PROBE = {0: "k_cg_pq", 8: "k_chebk<2,4", 9: "k_chebk<1,", 7: "k_mg_up_k<true", 1: "k_mg_down_k<true,3,false",
                        10: "k_mg_down_k<true,3,true", 2: "k_correct_flux<"}
 
 
@@ -55,17 +55,22 @@ def load_pmc_traffic():
                    if not any(w in f.name for w in ("komega", "graded", "annulus")))
     if not files:
         return None, {}
-    out = {}
+    # a probe id may cover several instantiations (k_cg_pq's first / later steps, k_chebk<1,4> and <1,6>): the mean over
+    # the rows that belong to it, weighted by the launches the counter pass saw
+    acc = {}
     for line in files[-1].read_text().splitlines():
         if line.startswith("#") or not line.strip():
             continue
         cols = line.split(";")
         for pid, key in PMC_KERNEL_OF_PROBE.items():
-            if cols[0].replace(" ", "").startswith(key.replace(" ", "")) and pid not in out:
+            if cols[0].replace(" ", "").startswith(key.replace(" ", "")):
                 try:
-                    out[pid] = float(cols[1])
+                    n = float(cols[8])
+                    tot, cnt = acc.get(pid, (0.0, 0.0))
+                    acc[pid] = (tot + float(cols[1]) * n, cnt + n)
                 except (IndexError, ValueError):
                     pass
+    out = {pid: tot / cnt for pid, (tot, cnt) in acc.items() if cnt > 0}
     return files[-1].name, out
 
 

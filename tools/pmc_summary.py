@@ -38,12 +38,16 @@ def algo_of(k):
     """algorithmic bytes per cell of a kernel name, template arguments of the lockstep forms ignored"""
     if k in ALGO:
         return ALGO[k]
-    m = re.match(r"k_chebk<(\d), 4", k)
-    if m:
+    m = re.match(r"k_chebk<(\d), [46]", k)
+    if m:       # (the six-iteration form moves the bytes of the four-iteration one)
         return 98.7 if m.group(1) == "2" else 64
-    m = re.match(r"k_cg_pq<\d+, (true|false), (true|false)(?:, (true|false))?>", k)
-    if m:       # first / second / later direction step of a solve; z in single precision
+    m = re.match(r"k_cg_pq<\d+, (true|false), (true|false)(?:, (true|false))?(?:, (true|false))?>", k)
+    if m:       # first / second / later direction step of a solve; z in single precision; x left alone (pcg_xsum)
+        if m.group(4) == "true":
+            return (40 if m.group(1) == "true" else 48) - (4 if m.group(3) == "true" else 0)
         return (40 if m.group(1) == "true" else (56 if m.group(2) == "true" else 64)) - (4 if m.group(3) == "true" else 0)
+    if k.startswith("k_cg_xsum"):
+        return 48       # five directions read, x written (a five-iteration solve)
     if k.startswith("k_cg_pq<"):
         return 58
     # fused V-cycle kernels: the last template argument says whether the face planes (-8 B) and the pre-smoothed
@@ -54,13 +58,13 @@ def algo_of(k):
     m = re.match(r"k_mg_down_k<true, 3, (true|false)(?:, \d+(?:, (true|false))?)?>", k)
     if m:
         return (50 if m.group(1) == "true" else 34) - (12 if m.group(2) == "true" else 0)
-    m = re.match(r"k_correct_flux<(true|false), (true|false)", k)
-    if m:       # correction + ghost cells + momentum right-hand sides: 17 planes read, 5 written (+ k, + lmin)
-        return 176 + (8 if m.group(1) == "true" else 0) + (8 if (m.group(2) == "true" and m.group(1) != "true") else 0)
-    m = re.match(r"k_flux_march<(\d), (true|false)(?:, (true|false))?", k)
+    m = re.match(r"k_correct_flux<(true|false), (true|false)(?:, \d+(?:, (true|false)(?:, (true|false))?)?)?", k)
+    if m:       # correction + ghost cells + momentum right-hand sides: 17 planes read, 5 written (+ k, + lmin); axis-aligned mesh: 13 read
+        return 176 + (8 if m.group(1) == "true" else 0) + (8 if (m.group(2) == "true" and m.group(1) != "true") else 0) - (32 if m.group(4) == "true" else 0)
+    m = re.match(r"k_flux_march<(\d), (true|false)(?:, (true|false)(?:, \d+(?:, (true|false))?)?)?", k)
     if m:
-        mode, kg, dt = m.group(1), m.group(2) == "true", m.group(3) == "true"
-        return {"0": 104, "1": 112, "2": 120, "3": 88, "4": 144}[mode] + (8 if (mode == "2" and (kg or dt)) else 0)
+        mode, kg, dt, rn = m.group(1), m.group(2) == "true", m.group(3) == "true", m.group(4) == "true"
+        return {"0": 104, "1": 112, "2": 120, "3": 88, "4": 144}[mode] + (8 if (mode == "2" and (kg or dt)) else 0) - (32 if (rn and mode != "3") else 0)
     return None
 
 
