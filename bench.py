@@ -674,8 +674,9 @@ def main():
                                    f"dt_max={cfg['time']['dt_max']:.3g}, rtol={args.tol:g}",
                        "precision_note": ("fp64 arithmetic, fp64 fields, fp64 Krylov recurrences and stopping tests; the "
                                           "multigrid PRECONDITIONER of the pressure solve stores its face coefficients, its "
-                                          "finest-level pre-smoothed iterate and its result z in fp32 (option mg_f32 = 1, "
-                                          "default): storage only, the converged p' is that of the fp64 system"
+                                          "finest-level pre-smoothed iterate, its result z and (one rank) the vectors of its "
+                                          "first coarse level in fp32 (options mg_f32 = 1, mg_c32 = 1, default): storage only, "
+                                          "the converged p' is that of the fp64 system"
                                           if "mg_f32=0" not in (args.tuning or "").replace(" ", "") else
                                           "fp64 arithmetic and storage throughout (mg_f32 = 0)"),
                        "cells_per_gpu": cells_gpu,
@@ -720,6 +721,9 @@ def main():
         # ((down + up) bytes per coarse cell x the cells of levels 1.. = 1/3 of the finest level's).
         f32 = "mg_f32=0" not in (args.tuning or "").replace(" ", "")
         coarse_bytes_per_vcycle = ((26.0 + 30.0) if f32 else (34.0 + 42.0)) / 3.0
+        if f32 and world == 1 and "mg_c32=0" not in (args.tuning or "").replace(" ", ""):
+            # the first coarse level keeps b and x in single precision (mg_c32): 17 + 21 B per level-1 cell
+            coarse_bytes_per_vcycle = (17.0 + 21.0) / 4.0 + (26.0 + 30.0) / 12.0
         n_solves = extra_steps * args.max_iter
         press_s = phases["press"] / n_solves
         mean_p_it = float(np.mean(p_its))

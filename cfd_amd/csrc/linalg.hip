@@ -1714,6 +1714,7 @@ struct SweepOm {
 struct MgRaw {
     double b, d, cw, ce, cs, cn, x, e, q;
     float fw, fe, fs, fn, fx;          // single-precision faces / iterate (F32 / XF forms)
+    float fb, fc;                      // single-precision right-hand side / coarse correction (VT forms)
     int row;
     bool valid;
 };
@@ -1729,7 +1730,12 @@ struct ResidFuse {
     int rr_slot = 0;                   // ... and the Ctx::scal slot their sum goes to (host side)
 };
 
-template <bool UP, bool RF = false, bool XO = false, bool F32 = false, bool XF = false>
+// VT (vector types of the first coarse level, option mg_c32): 0 every vector plane double; 1 this is the finest level over a
+// first coarse level that keeps its vectors in single precision (the coarse right-hand side goes out, the coarse
+// correction comes in as float); 2 this IS that level (b and x float, the next level's planes double).  Like the faces
+// and the finest level's x and z this is storage of the preconditioner only: 4096^2 cells of an 8192^2 mesh move 38 B
+// per cell and V-cycle instead of 74.  Float planes use the first half of the double plane (same element index).
+template <bool UP, bool RF = false, bool XO = false, bool F32 = false, bool XF = false, int VT = 0>
 __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, const Geo &g, const Geo &gc, const double *b,
                                          const double *x, const double *e, int j, bool cvalid, size_t colo, size_t coloc,
                                          MgRaw &R, const double *q = nullptr) {
@@ -1741,10 +1747,12 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
     if (UP) {
         if (XF) R.fx = reinterpret_cast<const float *>(x)[cc];
         else R.x = x[cc];
-        R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
+        if (VT == 1) R.fc = reinterpret_cast<const float *>(e)[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
+        else R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
     if (XO) R.x = x[cc];
-    R.b = b[cc];
+    if (VT == 2) R.fb = reinterpret_cast<const float *>(b)[cc];
+    else R.b = b[cc];
     if (RF) R.q = q[cc];
     const size_t cn_at = cc + north_offset(mr < g.nj + 2 * NG - 1, P);
     if (F32) {
@@ -1755,14 +1763,14 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
     R.d = (df.on && mr != g.nj + 2 * NG - 1) ? 0.0 : op.D[cc];
     R.row = (!df.on || mr == g.nj + 2 * NG - 1) ? -1000000 : js;
 }
-template <bool F32 = false>
+template <bool F32 = false, bool BF = false>
 __device__ __forceinline__ RowC mg_row(const MgRaw &R, const DiagFix &df, const OpDev &op, size_t colo) {
     const double cw = F32 ? (double)R.fw : R.cw, ce = F32 ? (double)R.fe : R.ce, cs = F32 ? (double)R.fs : R.cs, cn = F32 ? (double)R.fn : R.cn;
     const double d = R.row > -1000000 ? diag_from_faces(cw, ce, cs, cn, (int)colo - CO, R.row, df, op) : R.d;
-    return RowC{R.b, d, fast_rcp(d), cw, ce, cs, cn};
+    return RowC{BF ? (double)R.fb : R.b, d, fast_rcp(d), cw, ce, cs, cn};
 }
 
-template <bool FINE, int K, bool RF = false, int WPB = 4, bool F32 = false>
+template <bool FINE, int K, bool RF = false, int WPB = 4, bool F32 = false, int VT = 0>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
                                                         Geo gc, double *bc, ResidFuse rf = ResidFuse{}, int nts = 0) {
     const Geo g = op.g;
@@ -1796,7 +1804,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         // two rows of loads in flight per wave (see k_mg_up_k)
         const int jend = j1 + K;
         auto fetch = [&](int j, MgRaw &R) {
-            mg_fetch<false, RF, false, F32>(op, df, g, gc, b, nullptr, nullptr, j < jend ? j : jend - 1, cvalid, colo, 0, R, rf.q);
+            mg_fetch<false, RF, false, F32, false, VT>(op, df, g, gc, b, nullptr, nullptr, j < jend ? j : jend - 1, cvalid, colo, 0, R, rf.q);
         };
         auto trip = [&](int j, MgRaw cur) {
             if (RF) {
@@ -1807,7 +1815,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 if (own && out) store_stream(rf.rnew + (size_t)(j + NG) * P + colo, cur.b, nts & 1);
                 if (j >= j0 && j < j1 && out) rr2 += cur.b * cur.b;            // (r, r) of this slab's own cells
             }
-            RC[0] = mg_row<F32>(cur, df, op, colo);
+            RC[0] = mg_row<F32, VT == 2>(cur, df, op, colo);
             V[0] = cur.valid;
             X[1][2] = V[0] ? om.w[0] * RC[0].b * RC[0].inv : 0.0;          // first sweep from a zero guess
 #pragma unroll
@@ -1820,7 +1828,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                     if (row >= j0 && row < j1 && out) {
                         // finest level with single-precision faces: the pre-smoothed iterate, which only the post-smoothing
                         // pass reads, is stored in single precision too (same pitch in elements, first half of the plane)
-                        if (F32 && FINE) store_stream_f32(reinterpret_cast<float *>(x) + (size_t)(row + NG) * P + colo, (float)xn, nts & 1);
+                        if ((F32 && FINE) || VT == 2) store_stream_f32(reinterpret_cast<float *>(x) + (size_t)(row + NG) * P + colo, (float)xn, nts & 1);
                         else store_stream(x + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)xn : xn, nts & 1);
                     }
                 }
@@ -1832,7 +1840,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 rsum += res;
                 if (((jo - j0) & 1) || jo == j1 - 1) {
                     const double tot = rsum + lane_right(rsum);
-                    if (out && !((lane - K) & 1)) { const double cv = (iraw + 1 < g.ni) ? tot : rsum; bc[gc.cell(iraw >> 1, jo >> 1)] = (nts & 2) ? (double)(float)cv : cv; }
+                    if (out && !((lane - K) & 1)) {
+                        const double cv = (iraw + 1 < g.ni) ? tot : rsum;
+                        if (VT == 1) reinterpret_cast<float *>(bc)[gc.cell(iraw >> 1, jo >> 1)] = (float)cv;
+                        else bc[gc.cell(iraw >> 1, jo >> 1)] = (nts & 2) ? (double)(float)cv : cv;
+                    }
                     rsum = 0.0;
                 }
             }
@@ -1871,7 +1883,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
 
 // ZF (finest level, PCG): the result z goes out in single precision -- k_cg_pq reads it as such -- and (r, z) is taken
 // with the rounded value, the z the direction step will see.
-template <bool FINE, int K, int WPB = 4, bool F32 = false, bool ZF = false>
+template <bool FINE, int K, int WPB = 4, bool F32 = false, bool ZF = false, int VT = 0>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mg_up_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, const double *x, Geo gc,
                                                       const double *e, double gamma, SweepOm<K> om, double *xn, double *partials, int nts = 0) {
     const Geo g = op.g;
@@ -1905,12 +1917,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         // worked on; a fetch beyond the last row repeats it and is never consumed (no branch around the loads)
         const int jend = j1 + K;
         auto fetch = [&](int j, MgRaw &R) {
-            mg_fetch<true, false, false, F32, F32 && FINE>(op, df, g, gc, b, x, e, j < jend ? j : jend - 1, cvalid, colo, coloc, R);
+            mg_fetch<true, false, false, F32, (F32 && FINE) || VT == 2, VT>(op, df, g, gc, b, x, e, j < jend ? j : jend - 1, cvalid, colo, coloc, R);
         };
         auto trip = [&](int j, const MgRaw &cur) {
-            RC[0] = mg_row<F32>(cur, df, op, colo);
+            RC[0] = mg_row<F32, VT == 2>(cur, df, op, colo);
             V[0] = cur.valid;
-            X[0][2] = cur.valid ? ((F32 && FINE) ? (double)cur.fx : cur.x) + gamma * cur.e : 0.0;   // prolongated iterate on row j
+            X[0][2] = cur.valid ? (((F32 && FINE) || VT == 2) ? (double)cur.fx : cur.x) + gamma * (VT == 1 ? (double)cur.fc : cur.e) : 0.0;   // prolongated iterate on row j
 #pragma unroll
             for (int s2 = 1; s2 <= K; ++s2) {                               // sweep s2 on row j - s2
                 double v = jac(X[s2 - 1][1], X[s2 - 1][0], X[s2 - 1][2], RC[s2], om.w[s2 - 1]);
@@ -1923,6 +1935,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                             const float vf = (float)v;
                             store_stream_f32(reinterpret_cast<float *>(xn) + (size_t)(row + NG) * P + colo, vf, nts & 1);
                             dot += RC[K].b * (double)vf;
+                        } else if (VT == 2) {
+                            store_stream_f32(reinterpret_cast<float *>(xn) + (size_t)(row + NG) * P + colo, (float)v, nts & 1);
                         } else {
                             store_stream(xn + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)v : v, nts & 1);
                             if (FINE) dot += RC[K].b * v;
@@ -3754,6 +3768,11 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     int n_fused_levels = 0;
     const int lt = c->tail_lt;                   // levels [lt, nl) are cycled by k_mg_tail in one launch
     const int n_top = lt >= 0 ? lt : nl - 1;     // levels [0, n_top) run their own kernels
+    // the first coarse level keeps b and x in single precision (mg_fetch: VT) where the two finest levels both run the
+    // three-sweep kernels with single-precision faces (one rank: a cut would carry float halo rows)
+    const bool c32 = c->mg_c32 && c->mg_f32 && !c->mg_v32_emul && c->comm.nranks == 1 && KS == 3 && n_top >= 2 && nl >= 3 &&
+                     level_fusable(c, 0, c->levels[0].g, coarse_view(c, 1)) && level_fusable(c, 1, c->levels[1].g, coarse_view(c, 2)) &&
+                     level_op_mg(c, c->levels[0]).cif != nullptr && level_op_mg(c, c->levels[1]).cif != nullptr;
     for (int l = 0; l < n_top; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
@@ -3773,8 +3792,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 // rhs[0] is r_old here; the kernel leaves r = r_old - alpha q in rf->rnew, which the way up reads
                 if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
                 c->probe_begin(10);
-                LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<true, 3, true>), (k_mg_down_k<true, 3, true, 8>), (k_mg_down_k<true, 3, true, 4, true>), (k_mg_down_k<true, 3, true, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
-                c->probe_end(10, opm.cif ? 38.0 : 50.0);      // single precision: faces 8 B instead of 16, x 4 B instead of 8
+                if (c32) LAUNCH_WIDE(wide, (k_mg_down_k<true, 3, true, 4, true, 1>), (k_mg_down_k<true, 3, true, 8, true, 1>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g));
+                else LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<true, 3, true>), (k_mg_down_k<true, 3, true, 8>), (k_mg_down_k<true, 3, true, 4, true>), (k_mg_down_k<true, 3, true, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, *rf, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
+                c->probe_end(10, (opm.cif ? 38.0 : 50.0) - (c32 ? 1.0 : 0.0));      // single precision: faces 8 B instead of 16, x 4 B instead of 8 (coarse right-hand side: 1 instead of 2)
                 c->kc[KC_MG_DEFERRED_RESID] += 1;
                 rhs[0] = rf->rnew;
                 if (rf->rr_partials) {
@@ -3783,11 +3803,15 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 }
             } else if (l == 0) {
                 c->probe_begin(1);
-                if (KS == 3)
+                if (c32)
+                    LAUNCH_WIDE(wide, (k_mg_down_k<true, 3, false, 4, true, 1>), (k_mg_down_k<true, 3, false, 8, true, 1>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
+                else if (KS == 3)
                     LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<true, 3>), (k_mg_down_k<true, 3, false, 8>), (k_mg_down_k<true, 3, false, 4, true>), (k_mg_down_k<true, 3, false, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
                 else
                     hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
-                c->probe_end(1, (c->p_diag.on ? 34.0 : 42.0) - (opm.cif ? 12.0 : 0.0));
+                c->probe_end(1, (c->p_diag.on ? 34.0 : 42.0) - (opm.cif ? 12.0 : 0.0) - (c32 ? 1.0 : 0.0));
+            } else if (c32 && l == 1) {
+                LAUNCH_WIDE(wide, (k_mg_down_k<false, 3, false, 4, true, 2>), (k_mg_down_k<false, 3, false, 8, true, 2>), grid, opm, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
             } else if (KS == 3) {
                 LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<false, 3>), (k_mg_down_k<false, 3, false, 8>), (k_mg_down_k<false, 3, false, 4, true>), (k_mg_down_k<false, 3, false, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
             } else {
@@ -3899,17 +3923,25 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 c->probe_begin(7);
                 if (KS == 3 && opm.cif && z_f32) {
                     // the caller (fused PCG) takes z in single precision
-                    LAUNCH_WIDE(wide, (k_mg_up_k<true, 3, 4, true, true>), (k_mg_up_k<true, 3, 8, true, true>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e,
-                                c->mg_gamma, om3, oth[l], c->partials, c->nts(L.g));
+                    if (c32) LAUNCH_WIDE(wide, (k_mg_up_k<true, 3, 4, true, true, 1>), (k_mg_up_k<true, 3, 8, true, true, 1>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e,
+                                         c->mg_gamma, om3, oth[l], c->partials, c->nts(L.g));
+                    else LAUNCH_WIDE(wide, (k_mg_up_k<true, 3, 4, true, true>), (k_mg_up_k<true, 3, 8, true, true>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e,
+                                     c->mg_gamma, om3, oth[l], c->partials, c->nts(L.g));
                     *z_f32 = true;
-                } else if (KS == 3)
+                } else if (c32)
+                    LAUNCH_WIDE(wide, (k_mg_up_k<true, 3, 4, true, false, 1>), (k_mg_up_k<true, 3, 8, true, false, 1>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
+                                om3, oth[l], c->partials, c->nts(L.g));
+                else if (KS == 3)
                     LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_up_k<true, 3>), (k_mg_up_k<true, 3, 8>), (k_mg_up_k<true, 3, 4, true>), (k_mg_up_k<true, 3, 8, true>), grid, opm, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma,
                                 om3, oth[l], c->partials, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
                 else
                     hipLaunchKernelGGL((k_mg_up<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], cur[l], cg, e, c->mg_gamma, om, om2,
                                        oth[l], c->partials);
-                c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 12.0 : 0.0) - ((z_f32 && *z_f32) ? 4.0 : 0.0));
+                c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 12.0 : 0.0) - ((z_f32 && *z_f32) ? 4.0 : 0.0) - (c32 ? 1.0 : 0.0));
                 *dot_blocks = (int)grid.x;
+            } else if (c32 && l == 1) {
+                LAUNCH_WIDE(wide, (k_mg_up_k<false, 3, 4, true, false, 2>), (k_mg_up_k<false, 3, 8, true, false, 2>), grid, opm, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
+                            oth[l], c->partials, c->nts(L.g));
             } else if (KS == 3) {
                 LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_up_k<false, 3>), (k_mg_up_k<false, 3, 8>), (k_mg_up_k<false, 3, 4, true>), (k_mg_up_k<false, 3, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
                             oth[l], c->partials, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));

@@ -787,6 +787,41 @@ def test_six_fused_chebyshev_iterations_for_a_single_right_hand_side(turbulent, 
         assert rel_l2(mask_corners(a), mask_corners(b)) <= 1e-9
 
 
+def test_first_coarse_level_in_single_precision():
+    """Option `mg_c32` (default on, one rank): where the two finest multigrid levels both run the fused three-sweep kernels
+    with single-precision faces, the first coarse level keeps its right-hand side and its iterate in single precision as
+    well (38 instead of 74 B per coarse cell and V-cycle).  Storage of the preconditioner only: the V-cycle stays a
+    symmetric positive operator to single-precision rounding, PCG takes the same number of iterations and converges to the
+    solution of the double-precision system."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    rng = np.random.default_rng(5)
+    r1, r2 = rng.standard_normal((512, 512)), rng.standard_normal((512, 512))
+    r1 -= r1.mean()
+    r2 -= r2.mean()
+    for c32 in (1, 0):
+        dev, ctl, cfg = bench.setup_device(512, False, 2, 1e-8, 0, tuning={"mg_c32": c32})
+        dev.set_solver(1e-8, 200, 1e-11, 200, 1e-8, 200, True)
+        for step in range(4):
+            advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        st = dev.stats()
+        z1, z2 = dev.vcycle(r1), dev.vcycle(r2)
+        out[c32] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P)], st, z1, z2, dev.kernel_counts())
+        dev.close()
+    (f1, st1, za1, za2, k1), (f0, st0, zb1, zb2, k0) = out[1], out[0]
+    assert k1["mg_fused_levels_max"] >= 2 and abs(st1["p_iters"] - st0["p_iters"]) <= 1 and st1["p_relres"] <= 1e-11
+    sym = abs(np.vdot(r1, za2) - np.vdot(za1, r2)) / abs(np.vdot(r1, za2))
+    assert np.vdot(r1, za1) > 0.0 and np.vdot(r2, za2) > 0.0 and sym < 1e-5, sym
+    # the two preconditioners differ at the single-precision level, and only there
+    dz = np.abs(za1 - zb1).max() / np.abs(zb1).max()
+    assert 0.0 < dz < 1e-5, dz
+    for a, b in zip(f1, f0):
+        assert rel_l2(mask_corners(a), mask_corners(b)) <= 1e-8
+
+
 def _pcg_tail_pair(builder, fixup, tmp_path, extra=None):
     """The same case with the pressure solve as one launch (k_pcg_tail, default on small meshes) and as the launch-per-phase loop."""
     from cfd_amd import mesh as hip_mesh
