@@ -399,6 +399,7 @@ struct Ctx {
     bool bc_fresh = false;             // the ghosts of u, v, p [bc_cur] are those of k_flow_bc + exchange on the current values
     int bc_cur = -1, skip_fresh_bc = 1;
     bool mesh_halo2 = false;           // metric planes hold the neighbour slab's rows beyond the cuts (launch_correct_flux)
+    long mg_c32_min_cells = 1L << 18;  // ... from this many cells of the global level on
     int mg_c32 = 1;                    // fused V-cycle: the first coarse level keeps b and x in single precision (vcycle_impl: c32)
     int cheb_k6 = 1;                   // Chebyshev launches with one right-hand side left fuse six iterations (single rank, lockstep form)
     int rn_opt = 1, rn_state = -1;     // axis-aligned mesh (stencil.hip: rect_normals): option; -1 not looked at yet / 0 / 1

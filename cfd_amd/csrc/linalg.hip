@@ -3769,8 +3769,14 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     const int lt = c->tail_lt;                   // levels [lt, nl) are cycled by k_mg_tail in one launch
     const int n_top = lt >= 0 ? lt : nl - 1;     // levels [0, n_top) run their own kernels
     // the first coarse level keeps b and x in single precision (mg_fetch: VT) where the two finest levels both run the
-    // three-sweep kernels with single-precision faces (one rank: a cut would carry float halo rows)
-    const bool c32 = c->mg_c32 && c->mg_f32 && !c->mg_v32_emul && c->comm.nranks == 1 && KS == 3 && n_top >= 2 && nl >= 3 &&
+    // three-sweep kernels with single-precision faces
+    // (j-slabs: both levels slab-distributed, so that no gather touches a float plane; at a cut the float planes travel as
+    // planes of half the pitch, like the finest level's x)
+    // Only where the first coarse level is large (mg_c32_min_cells of the GLOBAL level, default 2^18 = the size from which a
+    // slab run replicates a level): the choice is then the same on one rank and on slabs, whose tails start at different levels
+    // on small meshes, and the slab V-cycle stays the single-rank V-cycle.
+    const long l1_cells = nl >= 2 ? (long)c->levels[1].g.ni * c->levels[1].g.nj * (la >= 2 ? c->comm.nranks : 1) : 0;
+    const bool c32 = c->mg_c32 && l1_cells >= c->mg_c32_min_cells && c->mg_f32 && !c->mg_v32_emul && (c->comm.nranks == 1 || la >= 2) && KS == 3 && n_top >= 2 && nl >= 3 &&
                      level_fusable(c, 0, c->levels[0].g, coarse_view(c, 1)) && level_fusable(c, 1, c->levels[1].g, coarse_view(c, 2)) &&
                      level_op_mg(c, c->levels[0]).cif != nullptr && level_op_mg(c, c->levels[1]).cif != nullptr;
     for (int l = 0; l < n_top; ++l) {
@@ -3787,7 +3793,11 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             const dim3 grid(march_grid(mgeo, wide));
             if (++n_fused_levels > c->kc[KC_MG_FUSED_LEVELS_MAX]) c->kc[KC_MG_FUSED_LEVELS_MAX] = n_fused_levels;
             if (l == 0 && rf) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rf->q)));      // r_old's rows are there already
-            else if (!rhs_sent[l]) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rhs[l])));
+            else if (!rhs_sent[l]) {
+                Geo gb = L.g;
+                if (c32 && l == 1) gb.pitch /= 2;              // float right-hand side of the first coarse level
+                CFD_TRY(halo_exchange(c, gb, KS, const_cast<double *>(rhs[l])));
+            }
             if (l == 0 && rf) {
                 // rhs[0] is r_old here; the kernel leaves r = r_old - alpha q in rf->rnew, which the way up reads
                 if (KS != 3) { set_error("internal: fused residual update needs three sweeps per pass"); return CFD_E_STATE; }
@@ -3820,13 +3830,14 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             CFD_HIP(hipGetLastError());
             if (l < la && (L.g.cutlo || L.g.cuthi)) {
                 // (a single-precision x: rows of half the bytes, which is a plane of half the pitch to the exchange)
-                Geo gx = L.g;
-                if (l == 0 && opm.cif && KS == 3) gx.pitch /= 2;
+                Geo gx = L.g, gcb = C.g;
+                if ((l == 0 && opm.cif && KS == 3) || (c32 && l == 1)) gx.pitch /= 2;
+                if (c32 && l == 0) gcb.pitch /= 2;             // float right-hand side of the first coarse level
                 HaloSpec sp[2] = {{&gx, KS, cur[l]}, {nullptr, 0, nullptr}};
                 int ns = 1;
                 x_sent[l] = 1;
                 if (l + 1 < la && l + 2 < nl && level_fusable(c, l + 1, C.g, coarse_view(c, l + 2))) {
-                    sp[ns++] = HaloSpec{&C.g, KS, cb};
+                    sp[ns++] = HaloSpec{&gcb, KS, cb};
                     rhs_sent[l + 1] = 1;
                 }
                 CFD_TRY(halo_exchange_multi(c, ns, sp));
@@ -3908,7 +3919,11 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         // (whose neighbouring rows are the halo), or the exchanged slab plane
         const double *e = cur[l + 1];
         if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
-        else if (l + 1 < la) CFD_TRY(halo_exchange(c, C.g, level_fusable(c, l, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
+        else if (l + 1 < la) {
+            Geo ge = C.g;
+            if (c32 && l == 0) ge.pitch /= 2;                  // float iterate of the first coarse level
+            CFD_TRY(halo_exchange(c, ge, level_fusable(c, l, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
+        }
         if (level_fusable(c, l, L.g, cg)) {
             MarchGeo mgeo = march_geo_k(L.g, KS, c->march_ls_model != 0);
             mgeo.xcd = KS == 3 ? c->xcd_map : 0;
@@ -3916,7 +3931,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             const dim3 grid(march_grid(mgeo, wide));
             if (!x_sent[l]) {
                 Geo gx = L.g;
-                if (l == 0 && opm.cif && KS == 3) gx.pitch /= 2;
+                if ((l == 0 && opm.cif && KS == 3) || (c32 && l == 1)) gx.pitch /= 2;
                 CFD_TRY(halo_exchange(c, gx, KS, cur[l]));
             }
             if (l == 0) {

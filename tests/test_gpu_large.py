@@ -802,7 +802,7 @@ def test_first_coarse_level_in_single_precision():
     r1 -= r1.mean()
     r2 -= r2.mean()
     for c32 in (1, 0):
-        dev, ctl, cfg = bench.setup_device(512, False, 2, 1e-8, 0, tuning={"mg_c32": c32})
+        dev, ctl, cfg = bench.setup_device(512, False, 2, 1e-8, 0, tuning={"mg_c32": c32, "mg_c32_min_cells": 1024})
         dev.set_solver(1e-8, 200, 1e-11, 200, 1e-8, 200, True)
         for step in range(4):
             advance_one_step(dev, ctl, step)

@@ -57,6 +57,7 @@ def _run(case, world, out_dir, min_rows=16, mode="gloo"):
 @pytest.mark.parametrize("case,world,min_rows", [
     ("channel_komega_48x64", 2, 16), ("channel_komega_48x64", 4, 16), ("channel_lam_64x128", 2, 16),
     ("channel_lam_64x128", 2, 512),      # production threshold: only the finest level is slab-distributed
+    ("channel_lam_256x256", 2, 16), ("channel_lam_256x256", 4, 16),     # float vectors of the first coarse level across the cuts
     ("inlet_outlet_40x32", 2, 16), ("couette_piso_24x32", 2, 16), ("half_cylinder_komega_24x32", 2, 16),
     # Menter SST on slabs: caches, wall distance and cell-centre differences across the cuts
     ("channel_sst_48x64", 2, 16), ("channel_sst_48x64", 4, 16), ("half_cylinder_sst_24x32", 2, 16),
@@ -164,7 +165,9 @@ def test_slab_mesh_from_rect(world, tmp_path):
     assert np.all(res["worst"] <= 1e-12), res["worst"]
 
 
-@pytest.mark.parametrize("case,world", [("channel_lam_64x128", 2), ("channel_komega_48x64", 2), ("channel_komega_48x64", 4)])
+@pytest.mark.parametrize("case,world", [("channel_lam_64x128", 2), ("channel_komega_48x64", 2), ("channel_komega_48x64", 4),
+                                        # two fused levels above the tail, the first coarse one with float vectors (mg_c32)
+                                        ("channel_lam_256x256", 2), ("channel_lam_256x256", 4)])
 def test_fused_kernels_across_cuts(case, world, tmp_path):
     """The fused kernels read up to four halo rows of the neighbour slab: one V(3,3) cycle on a random
     right-hand side agrees with the single-rank cycle to rounding, and one SIMPLE iteration takes the same
