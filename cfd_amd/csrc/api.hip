@@ -679,7 +679,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "pcg_tail_cells") { if (iv < 0 || iv > TAIL_MAX_CELLS) { set_error("pcg_tail_cells: 0 .. %d", TAIL_MAX_CELLS); return CFD_E_ARG; } c->pcg_tail_cells = iv; c->p_built = false; }
     else if (n == "speculate") c->speculate = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "pcg_xsum") c->pcg_xsum = iv ? 1 : 0;
-    else if (n == "rect_normals") c->rn_opt = iv ? 1 : 0;
+    else if (n == "rect_normals") c->rn_opt = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "mg_c32") c->mg_c32 = iv ? 1 : 0;
     else if (n == "mg_c32_min_cells") c->mg_c32_min_cells = iv < 0 ? 0 : iv;
     else if (n == "cheb_k6") c->cheb_k6 = iv ? 1 : 0;

@@ -402,7 +402,7 @@ struct Ctx {
     long mg_c32_min_cells = 1L << 18;  // ... from this many cells of the global level on
     int mg_c32 = 1;                    // fused V-cycle: the first coarse level keeps b and x in single precision (vcycle_impl: c32)
     int cheb_k6 = 1;                   // Chebyshev launches with one right-hand side left fuse six iterations (single rank, lockstep form)
-    int rn_opt = 1, rn_state = -1;     // axis-aligned mesh (stencil.hip: rect_normals): option; -1 not looked at yet / 0 / 1
+    int rn_opt = 2, rn_state = -1;     // axis-aligned mesh (stencil.hip: rect_normals): option (cap); -1 not looked at yet / 0 / 1 / 2
     int pcg_xsum = 1;                  // fused MG-PCG: x summed from the kept directions when the solve ends (k_cg_xsum) instead of updated every step
     int fuse_correct = 1;              // correction + boundary fill + closing flux pass in one marching kernel where correct_flux_ok()
     int per_i = 0, per_j = 0, wrap_p_i = 0, wrap_p_j = 0;
@@ -636,7 +636,7 @@ inline double global_cells(const Ctx *c) {
 }
 
 // linalg.hip
-bool rect_normals(Ctx *c);
+int rect_normals(Ctx *c);
 int sum_finish(Ctx *c, const double *partials, int nblocks, int nq, double *out);   // + all-reduce over slabs
 int reduce_finish(Ctx *c, int nq, int scal_off);       // partials -> scal[scal_off .. +nq)
 int read_scalars(Ctx *c, int off, int n, double *host);

@@ -522,7 +522,7 @@ constexpr int WIDE_FLUX = 128;       // Ctx::wide_mask bit of the flux kernels
 // is the neighbour's).  Zero on every rank -> the marching flux kernels take n_ix = S_i, n_jy = S_j, n_iy = n_jx = 0 from
 // the area planes (template argument RN) and leave the four normal planes alone.
 __global__ void k_rect_normals(Geo g, MeshDev m, double *partials, int tiles_x, int tiles) {
-    double a = 0.0;
+    double a = 0.0, a2 = 0.0;
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int i = (tile % tiles_x) * 64 + threadIdx.x, j = (tile / tiles_x) * 4 + threadIdx.y;
         if (i >= g.ni || j >= g.nj) continue;
@@ -531,25 +531,35 @@ __global__ void k_rect_normals(Geo g, MeshDev m, double *partials, int tiles_x, 
         if (i == g.ni - 1) bad |= (m.nix[c + 1] != m.si[c + 1]) | (m.niy[c + 1] != 0.0);
         if (j == g.nj - 1 && !g.cuthi) bad |= (m.njx[c + g.pitch] != 0.0) | (m.njy[c + g.pitch] != m.sj[c + g.pitch]);
         a += bad ? 1.0 : 0.0;
+        // separable areas: S_i of a row equals the row's first entry (face ni included), S_j of a column the column's entry
+        // in row 0 (row nj included: the top face row or, at a cut, the neighbour's row 0 -- which chains the ranks' rows 0)
+        const size_t r0 = g.cell(0, j), c0 = g.cell(i, 0);
+        int sep = (m.si[c] != m.si[r0]) | (m.sj[c] != m.sj[c0]);
+        if (i == g.ni - 1) sep |= (m.si[c + 1] != m.si[r0]);
+        if (j == g.nj - 1) sep |= (m.sj[c + g.pitch] != m.sj[c0]);
+        a2 += sep ? 1.0 : 0.0;
     }
     a = block_sum_256(a);
-    if (threadIdx.x == 0 && threadIdx.y == 0) partials[blockIdx.x] = a;
+    __syncthreads();
+    a2 = block_sum_256(a2);
+    if (threadIdx.x == 0 && threadIdx.y == 0) { partials[blockIdx.x] = a; partials[MAX_PARTIALS + blockIdx.x] = a2; }
 }
 // evaluated once per mesh, at the first marching flux pass (every rank gets there at the same point of the run: the sum
 // is all-reduced over the slabs); option rect_normals = 0 keeps the general kernels
-bool rect_normals(Ctx *c) {
-    if (!c->rn_opt) return false;
+// 0: general kernels, 1: normals from the area planes, 2: ... and separable areas (option rect_normals = 0 / 1 / 2 caps it)
+int rect_normals(Ctx *c) {
+    if (!c->rn_opt) return 0;
     if (c->rn_state < 0) {
         int tx;
         const int tiles = tiles_of(c->g, tx), nb = red_blocks(tiles);
         hipLaunchKernelGGL(k_rect_normals, dim3(nb), block2d(), 0, c->stream, c->g, c->mesh(), c->partials, tx, tiles);
-        double bad = 1.0;
-        if (hipGetLastError() != hipSuccess || sum_finish(c, c->partials, nb, 1, c->scal + 54) != CFD_OK ||
-            read_scalars(c, 54, 1, &bad) != CFD_OK)
-            bad = 1.0;
-        c->rn_state = bad == 0.0 ? 1 : 0;
+        double bad[2] = {1.0, 1.0};
+        if (hipGetLastError() != hipSuccess || sum_finish(c, c->partials, nb, 2, c->scal + 54) != CFD_OK ||
+            read_scalars(c, 54, 2, bad) != CFD_OK)
+            bad[0] = 1.0;
+        c->rn_state = bad[0] == 0.0 ? (bad[1] == 0.0 ? 2 : 1) : 0;
     }
-    return c->rn_state == 1;
+    return c->rn_state < c->rn_opt ? c->rn_state : c->rn_opt;
 }
 
 // lockstep form for the momentum / pressure right-hand-side passes on meshes with enough strips
@@ -606,10 +616,14 @@ struct MomArgs {
 #define FX_NJX(R) (RN ? 0.0 : (R).njx)
 #define FX_NJY(R) (RN ? (R).sj : (R).njy)
 // WPB = 8: lockstep workgroups of eight neighbouring strips (MarchItems, internal.h)
-template <int MODE, bool KG, bool DT = false, int WPB = 4, bool RNA = false>
+// RNA = 2: the areas are separable as well -- S_i the same along a row, S_j the same along a column, bit for bit (tensor-
+// product node grids; checked with the normals) -- so S_i is one value per row (every lane loads the row's first entry)
+// and S_j one register per lane and work item: another 16 B per cell less.
+template <int MODE, bool KG, bool DT = false, int WPB = 4, int RNA = 0>
 __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxIn f, FluxMarch fm, MomArgs ma, double *bout,
                                                          double *partials) {
-    constexpr bool RN = RNA && MODE != 3;         // (the time-step pass reads no area planes)
+    constexpr bool RN = RNA >= 1 && MODE != 3;         // (the time-step pass reads no area planes)
+    constexpr bool SEP = RNA == 2 && MODE != 3;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const size_t P = g.pitch;
     const int rc = MODE == 3 ? 0 : f.rc;
@@ -626,8 +640,10 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
         const bool out = lane >= 1 && lane <= FXW && iraw < g.ni && active;
         const bool ilo = iraw == 0, ihi = iraw == g.ni;
         const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
+        const double sj_col = SEP ? m.sj[(size_t)NG * P + colo] : 0.0;
         auto fetch = [&](int j, FluxRow &R) {
             const size_t c = (size_t)(j + NG) * P + colo;
+            const size_t c_si = SEP ? (size_t)(j + NG) * P + CO : c;
             R.u = f.u[c]; R.v = f.v[c];
             R.wri = m.wri[c]; R.wnj = m.wnj[c];
             if (RN) { R.nix = 0.0; R.niy = 0.0; R.njx = 0.0; R.njy = 0.0; }
@@ -643,11 +659,11 @@ __global__ __launch_bounds__(64 * WPB) void k_flux_march(Geo g, MeshDev m, FluxI
                 R.nut = ma.nut[c];
                 R.p = f.p[c] + (2.0 / 3.0) * R.k;        // p_eff (peff())
                 R.ap = rc ? f.ap[c] : 1.0;
-                R.si = m.si[c]; R.sj = m.sj[c];
+                R.si = m.si[c_si]; R.sj = SEP ? sj_col : m.sj[c];
             } else {
                 R.p = f.p[c];
                 R.ap = rc ? f.ap[c] : 1.0;
-                R.si = m.si[c]; R.sj = m.sj[c];
+                R.si = m.si[c_si]; R.sj = SEP ? sj_col : m.sj[c];
                 R.k = KG ? (2.0 / 3.0) * ma.kgrad[c] : 0.0;
                 if (DT) R.lmin = ma.use_diff ? m.lmin[c] : 1.0;
             }
@@ -947,9 +963,10 @@ __device__ __forceinline__ void bc_ghost(const FlowBCSide &s, int t, double ui, 
 
 // RN: see k_flux_march.  The area S_j of a row's south face then travels with the early part of the row (CorrE, in place
 // of n_jy), so that the correction of row r still waits for no load of row r + 1's late part.
-template <bool KG, bool DT, int WPB, bool LOCK = (WPB > 4), bool RN = false>
+template <bool KG, bool DT, int WPB, bool LOCK = (WPB > 4), int RNA = 0>
 __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, CorrIn ci, FlowBCDev bc, FluxMarch fm, MomArgs ma,
                                                            double *partials) {
+    constexpr bool RN = RNA >= 1, SEP = RNA == 2;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t P = g.pitch;
     const int rc = ci.rc;
@@ -976,12 +993,13 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
         const bool glo = !ci.per_i && iraw == -1, ghi = !ci.per_i && iraw == g.ni;      // ghost lanes of a non-periodic i-direction
         const int j0 = seg * fm.Ls, j1 = min(j0 + fm.Ls, g.nj);
         const int rlo = g.cutlo ? -2 : -1, rhi = g.cuthi ? g.nj + 1 : g.nj;      // rows the planes hold
+        const double sj_col = SEP ? m.sj[(size_t)NG * P + colw] : 0.0;
         auto fetchE = [&](int r, CorrE &R) {
             const int rr = r < rlo ? rlo : (r > rhi ? rhi : r);
             const size_t c = (size_t)(rr + NG) * P + colw;
             R.pc = ci.pc[(size_t)(rr + NG) * P + colp];
             R.wnj = m.wnj[c];
-            if (RN) { R.njx = 0.0; R.njy = m.sj[c]; }          // (S_j in the slot of n_jy)
+            if (RN) { R.njx = 0.0; R.njy = SEP ? sj_col : m.sj[c]; }          // (S_j in the slot of n_jy)
             else { R.njx = m.njx[c]; R.njy = m.njy[c]; }
         };
         auto kload = [&](int rr) -> double {
@@ -992,14 +1010,15 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             const size_t c = (size_t)(rr + NG) * P + colw;
             R.us = ci.us[c]; R.vs = ci.vs[c]; R.u0 = ci.u0[c]; R.v0 = ci.v0[c]; R.p0 = ci.p0[c];
             R.ap = ci.ap[c]; R.vol = m.vol[c];
-            R.wri = m.wri[c]; R.si = m.si[c];
+            R.wri = m.wri[c]; R.si = m.si[SEP ? (size_t)(rr + NG) * P + CO : c];
             if (RN) { R.nix = 0.0; R.niy = 0.0; R.sj = 0.0; }
             else { R.nix = m.nix[c]; R.niy = m.niy[c]; R.sj = m.sj[c]; }
             R.k = kload(rr);
             R.lmin = (DT && ma.use_diff) ? m.lmin[c] : 1.0;
             if (ihi) {       // the west face of this lane is face ni, whose entries are separate from face 0's
                 const size_t ce = (size_t)(rr + NG) * P + (size_t)(g.ni + CO);
-                R.wri = m.wri[ce]; R.si = m.si[ce];
+                R.wri = m.wri[ce];
+                if (!SEP) R.si = m.si[ce];
                 if (!RN) { R.nix = m.nix[ce]; R.niy = m.niy[ce]; }
             }
         };
@@ -1019,7 +1038,8 @@ __global__ __launch_bounds__(64 * WPB) void k_correct_flux(Geo g, MeshDev m, Cor
             if (ihi && ci.per_i) {
                 const size_t c0 = (size_t)(r + NG) * P + colw;
                 wri = m.wri[c0];
-                if (RN) nix = m.si[c0];
+                if (SEP) nix = Lb.si;
+                else if (RN) nix = m.si[c0];
                 else { nix = m.nix[c0]; niy = m.niy[c0]; }
             }
             const double pw = (1.0 - wri) * pW + wri * pcc;
@@ -1381,16 +1401,19 @@ int launch_correct_flux(Ctx *c, double dt, double ru, double rv, double rp, bool
     const bool dt_too = c->dt_lookahead && c->dtp_set && (c->dtp_use_cfl || !c->turbulent);
     // u*, v*, u0, v0, p0, p', a_P, V, w x 2, n x 4, S x 2 read; u, v, p, b_u, b_v written (+ k, + lmin)
     // (axis-aligned mesh: the four normal planes are not read)
-    const bool rn = rect_normals(c);
-    c->last_rhs_bytes = 176.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0);
+    const int rn = rect_normals(c);
+    c->last_rhs_bytes = 176.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0) - (rn == 2 ? 16.0 : 0.0);
     if (dt_too) {
         ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
         ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
 #define LAUNCH_CF(KGv, DTv)                                                                                                   \
     do {                                                                                                                     \
-        if (rn) {                                                                                                            \
-            if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
-            else LAUNCH_FLUX(fm, (k_correct_flux<KGv, DTv, 4, false, true>), (k_correct_flux<KGv, DTv, 8, true, true>), c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+        if (rn == 2) {                                                                                                       \
+            if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true, 2>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+            else LAUNCH_FLUX(fm, (k_correct_flux<KGv, DTv, 4, false, 2>), (k_correct_flux<KGv, DTv, 8, true, 2>), c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+        } else if (rn) {                                                                                                     \
+            if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true, 1>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
+            else LAUNCH_FLUX(fm, (k_correct_flux<KGv, DTv, 4, false, 1>), (k_correct_flux<KGv, DTv, 8, true, 1>), c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
         } else if (lock4) hipLaunchKernelGGL((k_correct_flux<KGv, DTv, 4, true>), dim3(fm.blocks), dim3(256), 0, c->stream, c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials); \
         else LAUNCH_FLUX(fm, (k_correct_flux<KGv, DTv, 4>), (k_correct_flux<KGv, DTv, 8>), c->g, c->mesh(), ci, c->fbc, fm, ma, c->partials);                       \
     } while (0)
@@ -1480,11 +1503,12 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         const bool dt_too = cont && c->dt_lookahead && c->dtp_set && (c->dtp_use_cfl || !c->turbulent);
         // 13 planes read (u, v, p, a_P, V, w x 2, n x 4, S x 2), b_u, b_v written; + k in turbulent runs; + lmin for the
         // diffusive minimum taken ahead
-        const bool rn = rect_normals(c);
-        c->last_rhs_bytes = 120.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0);
+        const int rn = rect_normals(c);
+        c->last_rhs_bytes = 120.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0) - (rn == 2 ? 16.0 : 0.0);
 #define LAUNCH_FM2(KGv, DTv)                                                                                                  \
     do {                                                                                                                     \
-        if (rn) LAUNCH_FLUX(fm, (k_flux_march<2, KGv, DTv, 4, true>), (k_flux_march<2, KGv, DTv, 8, true>), c->g, c->mesh(), f, fm, ma, (double *)nullptr, c->partials); \
+        if (rn == 2) LAUNCH_FLUX(fm, (k_flux_march<2, KGv, DTv, 4, 2>), (k_flux_march<2, KGv, DTv, 8, 2>), c->g, c->mesh(), f, fm, ma, (double *)nullptr, c->partials); \
+        else if (rn) LAUNCH_FLUX(fm, (k_flux_march<2, KGv, DTv, 4, 1>), (k_flux_march<2, KGv, DTv, 8, 1>), c->g, c->mesh(), f, fm, ma, (double *)nullptr, c->partials); \
         else LAUNCH_FLUX(fm, (k_flux_march<2, KGv, DTv>), (k_flux_march<2, KGv, DTv, 8>), c->g, c->mesh(), f, fm, ma, (double *)nullptr, c->partials); \
     } while (0)
         if (dt_too) {
@@ -1605,8 +1629,12 @@ int launch_turb_rhs(Ctx *c, double dt) {
         MomArgs ma{c->k, c->ti, c->tj, 1.0 / dt, 0.0, 0.0, c->per_i, c->per_j, c->bu, c->bv};
         ma.nts = c->nts();
         ma.nut = c->nut; ma.omega = c->omega;
-        if (rect_normals(c))
-            LAUNCH_FLUX(fm, (k_flux_march<4, false, false, 4, true>), (k_flux_march<4, false, false, 8, true>), c->g, c->mesh(), f, fm, ma,
+        const int rn = rect_normals(c);
+        if (rn == 2)
+            LAUNCH_FLUX(fm, (k_flux_march<4, false, false, 4, 2>), (k_flux_march<4, false, false, 8, 2>), c->g, c->mesh(), f, fm, ma,
+                        (double *)nullptr, c->partials);
+        else if (rn)
+            LAUNCH_FLUX(fm, (k_flux_march<4, false, false, 4, 1>), (k_flux_march<4, false, false, 8, 1>), c->g, c->mesh(), f, fm, ma,
                         (double *)nullptr, c->partials);
         else
             LAUNCH_FLUX(fm, (k_flux_march<4, false>), (k_flux_march<4, false, false, 8>), c->g, c->mesh(), f, fm, ma,
@@ -1684,11 +1712,12 @@ int launch_pressure_rhs(Ctx *c, const double *u, const double *v, const double *
         ma.nts = c->nts();
         c->kc[KC_FLUX_MARCH] += 1;
         if (fm.nstrips > 1) c->kc[KC_FLUX_MARCH_MULTISTRIP] += 1;
-        const bool rn = rect_normals(c);
+        const int rn = rect_normals(c);
         c->probe_begin(13);
-        if (rn) LAUNCH_FLUX(fm, (k_flux_march<1, false, false, 4, true>), (k_flux_march<1, false, false, 8, true>), c->g, c->mesh(), f, fm, ma, b, c->partials);
+        if (rn == 2) LAUNCH_FLUX(fm, (k_flux_march<1, false, false, 4, 2>), (k_flux_march<1, false, false, 8, 2>), c->g, c->mesh(), f, fm, ma, b, c->partials);
+        else if (rn) LAUNCH_FLUX(fm, (k_flux_march<1, false, false, 4, 1>), (k_flux_march<1, false, false, 8, 1>), c->g, c->mesh(), f, fm, ma, b, c->partials);
         else LAUNCH_FLUX(fm, (k_flux_march<1, false>), (k_flux_march<1, false, false, 8>), c->g, c->mesh(), f, fm, ma, b, c->partials);
-        c->probe_end(13, rn ? 80.0 : 112.0);       // u, v, p, a_P, V, w x 2, n x 4 (not on axis-aligned meshes), S x 2 read, b written
+        c->probe_end(13, rn == 2 ? 64.0 : (rn ? 80.0 : 112.0));       // u, v, p, a_P, V, w x 2, n x 4 (not on axis-aligned meshes), S x 2 read, b written
     } else {
         hipLaunchKernelGGL(k_pressure_rhs, grid2d(c->g.ni, c->g.nj), block2d(), 0, c->stream, c->g, c->mesh(), f, b);
     }

@@ -720,14 +720,16 @@ def test_pcg_solution_summed_from_the_kept_directions(n, p_tol, spec):
 def test_axis_aligned_meshes_leave_the_normal_planes_alone(kind):
     """On a mesh whose face area vectors are (S, 0) / (0, S) bit for bit (every rectangular mesh, graded or not; checked
     on the device once per mesh) the marching flux kernels take the normals from the area planes they read anyway and do
-    not read the four normal planes (option `rect_normals`, default on): the pressure right-hand side pass reports 80
-    algorithmic bytes per cell instead of 112, and every field is the one the general kernels give.  A curvilinear mesh
-    (annulus) keeps the general kernels."""
+    not read the four normal planes (option `rect_normals` >= 1): the pressure right-hand side pass reports 80 algorithmic
+    bytes per cell instead of 112.  Where the areas are separable too -- S_i one value per row, S_j one per column, as on
+    every tensor-product node grid -- they come from one entry per row / one register per lane (`rect_normals` = 2, the
+    default): 64 bytes.  Every field is the one the general kernels give, bit for bit.  A curvilinear mesh (annulus) keeps
+    the general kernels."""
     import bench
     from cfd_amd import _lib as L
     from cfd_amd.solver import advance_one_step
     out = {}
-    for rn in (1, 0):
+    for rn in (2, 1, 0):
         if kind == "annulus":
             dev, ctl, cfg = bench.setup_annulus(192, 96, 2, 1e-8, 0, tuning={"rect_normals": rn})
         else:
@@ -741,13 +743,16 @@ def test_axis_aligned_meshes_leave_the_normal_planes_alone(kind):
         names = (L.F_U, L.F_V, L.F_P) + ((L.F_K, L.F_OMEGA, L.F_NUT) if kind == "komega" else ())
         out[rn] = ([dev.download(f) for f in names], n, bpc, dev.kernel_counts())
         dev.close()
-    (f1, n1, b1, k1), (f0, n0, b0, k0) = out[1], out[0]
-    assert n1 == n0 > 0 and b0 == 112.0 and b1 == (112.0 if kind == "annulus" else 80.0), (n1, n0, b1, b0)
-    assert k1["flux_march"] == k0["flux_march"] > 0 and k1["correct_flux"] == k0["correct_flux"]
-    if kind != "annulus":
-        assert k1["correct_flux"] > 0
-    for a, b in zip(f1, f0):
-        assert np.array_equal(mask_corners(a), mask_corners(b)), np.abs(a - b).max()
+    f0, n0, b0, k0 = out[0]
+    assert n0 > 0 and b0 == 112.0 and k0["flux_march"] > 0
+    for rn, expect in ((1, 80.0), (2, 64.0)):
+        f1, n1, b1, k1 = out[rn]
+        assert n1 == n0 and b1 == (112.0 if kind == "annulus" else expect), (rn, n1, n0, b1)
+        assert k1["flux_march"] == k0["flux_march"] and k1["correct_flux"] == k0["correct_flux"]
+        if kind != "annulus":
+            assert k1["correct_flux"] > 0
+        for a, b in zip(f1, f0):
+            assert np.array_equal(mask_corners(a), mask_corners(b)), (rn, np.abs(a - b).max())
 
 
 @pytest.mark.parametrize("turbulent,spec", [(False, 1), (False, 0), (True, 1)])
