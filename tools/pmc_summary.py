@@ -52,19 +52,20 @@ def algo_of(k):
         return 58
     # fused V-cycle kernels: the last template argument says whether the face planes (-8 B) and the pre-smoothed
     # iterate (-4 B) are single precision
-    m = re.match(r"k_mg_up_k<true, 3(?:, \d+(?:, (true|false)(?:, (true|false))?)?)?>", k)
-    if m:       # ..., single-precision faces and x, single-precision z
-        return 42 - (12 if m.group(1) == "true" else 0) - (4 if m.group(2) == "true" else 0)
-    m = re.match(r"k_mg_down_k<true, 3, (true|false)(?:, \d+(?:, (true|false))?)?>", k)
+    m = re.match(r"k_mg_up_k<true, 3(?:, \d+(?:, (true|false)(?:, (true|false)(?:, (\d))?)?)?)?>", k)
+    if m:       # ..., single-precision faces and x, single-precision z, coarse correction read as float (VT = 1)
+        return 42 - (12 if m.group(1) == "true" else 0) - (4 if m.group(2) == "true" else 0) - (1 if m.group(3) == "1" else 0)
+    m = re.match(r"k_mg_down_k<true, 3, (true|false)(?:, \d+(?:, (true|false)(?:, (\d))?)?)?>", k)
+    if m:       # ..., coarse right-hand side written as float (VT = 1)
+        return (50 if m.group(1) == "true" else 34) - (12 if m.group(2) == "true" else 0) - (1 if m.group(3) == "1" else 0)
+    rna = {"true": 32, "1": 32, "2": 48}      # axis-aligned mesh: normals not read (-32); separable areas too (-48)
+    m = re.match(r"k_correct_flux<(true|false), (true|false)(?:, \d+(?:, (true|false)(?:, (true|false|\d))?)?)?", k)
+    if m:       # correction + ghost cells + momentum right-hand sides: 17 planes read, 5 written (+ k, + lmin)
+        return 176 + (8 if m.group(1) == "true" else 0) + (8 if (m.group(2) == "true" and m.group(1) != "true") else 0) - rna.get(m.group(4), 0)
+    m = re.match(r"k_flux_march<(\d), (true|false)(?:, (true|false)(?:, \d+(?:, (true|false|\d))?)?)?", k)
     if m:
-        return (50 if m.group(1) == "true" else 34) - (12 if m.group(2) == "true" else 0)
-    m = re.match(r"k_correct_flux<(true|false), (true|false)(?:, \d+(?:, (true|false)(?:, (true|false))?)?)?", k)
-    if m:       # correction + ghost cells + momentum right-hand sides: 17 planes read, 5 written (+ k, + lmin); axis-aligned mesh: 13 read
-        return 176 + (8 if m.group(1) == "true" else 0) + (8 if (m.group(2) == "true" and m.group(1) != "true") else 0) - (32 if m.group(4) == "true" else 0)
-    m = re.match(r"k_flux_march<(\d), (true|false)(?:, (true|false)(?:, \d+(?:, (true|false))?)?)?", k)
-    if m:
-        mode, kg, dt, rn = m.group(1), m.group(2) == "true", m.group(3) == "true", m.group(4) == "true"
-        return {"0": 104, "1": 112, "2": 120, "3": 88, "4": 144}[mode] + (8 if (mode == "2" and (kg or dt)) else 0) - (32 if (rn and mode != "3") else 0)
+        mode, kg, dt = m.group(1), m.group(2) == "true", m.group(3) == "true"
+        return {"0": 104, "1": 112, "2": 120, "3": 88, "4": 144}[mode] + (8 if (mode == "2" and (kg or dt)) else 0) - (rna.get(m.group(4), 0) if mode != "3" else 0)
     return None
 
 
