@@ -1730,9 +1730,10 @@ struct ResidFuse {
     int rr_slot = 0;                   // ... and the Ctx::scal slot their sum goes to (host side)
 };
 
-// VT (vector types of the first coarse level, option mg_c32): 0 every vector plane double; 1 this is the finest level over a
-// first coarse level that keeps its vectors in single precision (the coarse right-hand side goes out, the coarse
-// correction comes in as float); 2 this IS that level (b and x float, the next level's planes double).  Like the faces
+// VT (vector types of the first coarse levels, option mg_c32), two bits: 1 the NEXT level keeps its vectors in single
+// precision (the coarse right-hand side goes out, the coarse correction comes in as float); 2 THIS level does (b and x
+// float).  0 everywhere: every vector plane double; finest level over a float level: 1; a float level over a double one:
+// 2; over another float level: 3.  Like the faces
 // and the finest level's x and z this is storage of the preconditioner only: 4096^2 cells of an 8192^2 mesh move 38 B
 // per cell and V-cycle instead of 74.  Float planes use the first half of the double plane (same element index).
 template <bool UP, bool RF = false, bool XO = false, bool F32 = false, bool XF = false, int VT = 0>
@@ -1747,11 +1748,11 @@ __device__ __forceinline__ void mg_fetch(const OpDev &op, const DiagFix &df, con
     if (UP) {
         if (XF) R.fx = reinterpret_cast<const float *>(x)[cc];
         else R.x = x[cc];
-        if (VT == 1) R.fc = reinterpret_cast<const float *>(e)[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
+        if (VT & 1) R.fc = reinterpret_cast<const float *>(e)[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
         else R.e = e[(size_t)((js >> 1) + NG) * gc.pitch + coloc];
     }
     if (XO) R.x = x[cc];
-    if (VT == 2) R.fb = reinterpret_cast<const float *>(b)[cc];
+    if (VT & 2) R.fb = reinterpret_cast<const float *>(b)[cc];
     else R.b = b[cc];
     if (RF) R.q = q[cc];
     const size_t cn_at = cc + north_offset(mr < g.nj + 2 * NG - 1, P);
@@ -1815,7 +1816,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                 if (own && out) store_stream(rf.rnew + (size_t)(j + NG) * P + colo, cur.b, nts & 1);
                 if (j >= j0 && j < j1 && out) rr2 += cur.b * cur.b;            // (r, r) of this slab's own cells
             }
-            RC[0] = mg_row<F32, VT == 2>(cur, df, op, colo);
+            RC[0] = mg_row<F32, (VT & 2) != 0>(cur, df, op, colo);
             V[0] = cur.valid;
             X[1][2] = V[0] ? om.w[0] * RC[0].b * RC[0].inv : 0.0;          // first sweep from a zero guess
 #pragma unroll
@@ -1828,7 +1829,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                     if (row >= j0 && row < j1 && out) {
                         // finest level with single-precision faces: the pre-smoothed iterate, which only the post-smoothing
                         // pass reads, is stored in single precision too (same pitch in elements, first half of the plane)
-                        if ((F32 && FINE) || VT == 2) store_stream_f32(reinterpret_cast<float *>(x) + (size_t)(row + NG) * P + colo, (float)xn, nts & 1);
+                        if ((F32 && FINE) || (VT & 2)) store_stream_f32(reinterpret_cast<float *>(x) + (size_t)(row + NG) * P + colo, (float)xn, nts & 1);
                         else store_stream(x + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)xn : xn, nts & 1);
                     }
                 }
@@ -1842,7 +1843,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                     const double tot = rsum + lane_right(rsum);
                     if (out && !((lane - K) & 1)) {
                         const double cv = (iraw + 1 < g.ni) ? tot : rsum;
-                        if (VT == 1) reinterpret_cast<float *>(bc)[gc.cell(iraw >> 1, jo >> 1)] = (float)cv;
+                        if (VT & 1) reinterpret_cast<float *>(bc)[gc.cell(iraw >> 1, jo >> 1)] = (float)cv;
                         else bc[gc.cell(iraw >> 1, jo >> 1)] = (nts & 2) ? (double)(float)cv : cv;
                     }
                     rsum = 0.0;
@@ -1917,12 +1918,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
         // worked on; a fetch beyond the last row repeats it and is never consumed (no branch around the loads)
         const int jend = j1 + K;
         auto fetch = [&](int j, MgRaw &R) {
-            mg_fetch<true, false, false, F32, (F32 && FINE) || VT == 2, VT>(op, df, g, gc, b, x, e, j < jend ? j : jend - 1, cvalid, colo, coloc, R);
+            mg_fetch<true, false, false, F32, (F32 && FINE) || (VT & 2), VT>(op, df, g, gc, b, x, e, j < jend ? j : jend - 1, cvalid, colo, coloc, R);
         };
         auto trip = [&](int j, const MgRaw &cur) {
-            RC[0] = mg_row<F32, VT == 2>(cur, df, op, colo);
+            RC[0] = mg_row<F32, (VT & 2) != 0>(cur, df, op, colo);
             V[0] = cur.valid;
-            X[0][2] = cur.valid ? (((F32 && FINE) || VT == 2) ? (double)cur.fx : cur.x) + gamma * (VT == 1 ? (double)cur.fc : cur.e) : 0.0;   // prolongated iterate on row j
+            X[0][2] = cur.valid ? (((F32 && FINE) || (VT & 2)) ? (double)cur.fx : cur.x) + gamma * ((VT & 1) ? (double)cur.fc : cur.e) : 0.0;   // prolongated iterate on row j
 #pragma unroll
             for (int s2 = 1; s2 <= K; ++s2) {                               // sweep s2 on row j - s2
                 double v = jac(X[s2 - 1][1], X[s2 - 1][0], X[s2 - 1][2], RC[s2], om.w[s2 - 1]);
@@ -1935,7 +1936,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))
                             const float vf = (float)v;
                             store_stream_f32(reinterpret_cast<float *>(xn) + (size_t)(row + NG) * P + colo, vf, nts & 1);
                             dot += RC[K].b * (double)vf;
-                        } else if (VT == 2) {
+                        } else if (VT & 2) {
                             store_stream_f32(reinterpret_cast<float *>(xn) + (size_t)(row + NG) * P + colo, (float)v, nts & 1);
                         } else {
                             store_stream(xn + (size_t)(row + NG) * P + colo, (nts & 2) ? (double)(float)v : v, nts & 1);
@@ -3772,13 +3773,23 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
     // three-sweep kernels with single-precision faces
     // (j-slabs: both levels slab-distributed, so that no gather touches a float plane; at a cut the float planes travel as
     // planes of half the pitch, like the finest level's x)
-    // Only where the first coarse level is large (mg_c32_min_cells of the GLOBAL level, default 2^18 = the size from which a
-    // slab run replicates a level): the choice is then the same on one rank and on slabs, whose tails start at different levels
-    // on small meshes, and the slab V-cycle stays the single-rank V-cycle.
-    const long l1_cells = nl >= 2 ? (long)c->levels[1].g.ni * c->levels[1].g.nj * (la >= 2 ? c->comm.nranks : 1) : 0;
-    const bool c32 = c->mg_c32 && l1_cells >= c->mg_c32_min_cells && c->mg_f32 && !c->mg_v32_emul && (c->comm.nranks == 1 || la >= 2) && KS == 3 && n_top >= 2 && nl >= 3 &&
-                     level_fusable(c, 0, c->levels[0].g, coarse_view(c, 1)) && level_fusable(c, 1, c->levels[1].g, coarse_view(c, 2)) &&
-                     level_op_mg(c, c->levels[0]).cif != nullptr && level_op_mg(c, c->levels[1]).cif != nullptr;
+    // Only levels with MORE than mg_c32_min_cells cells of the GLOBAL level (default 2^18 = the size up to which a slab run
+    // replicates a level, far above what a tail takes): the choice is then the same on one rank and on slabs, whose tails
+    // start at different levels on small meshes, and the slab V-cycle stays the single-rank V-cycle.
+    // nf32 = number of coarse levels (1 .. nf32) with float vectors: at most two (the second one is 1 / 16 of the finest).
+    int nf32 = 0;
+    if (c->mg_c32 && c->mg_f32 && !c->mg_v32_emul && KS == 3 && level_fusable(c, 0, c->levels[0].g, coarse_view(c, 1)) &&
+        level_op_mg(c, c->levels[0]).cif != nullptr) {
+        for (int l = 1; l <= c->mg_c32 && l < n_top && l + 1 < nl; ++l) {
+            const long cells = (long)c->levels[l].g.ni * c->levels[l].g.nj * (l < la ? c->comm.nranks : 1);
+            if (cells <= c->mg_c32_min_cells || !(c->comm.nranks == 1 || l < la) || !level_fusable(c, l, c->levels[l].g, coarse_view(c, l + 1)) ||
+                level_op_mg(c, c->levels[l]).cif == nullptr)
+                break;
+            nf32 = l;
+        }
+    }
+    const bool c32 = nf32 >= 1;
+    auto own32 = [&](int l) { return l >= 1 && l <= nf32; };        // level l keeps b and x as float
     for (int l = 0; l < n_top; ++l) {
         const Level &L = c->levels[l];
         const Level &C = c->levels[l + 1];
@@ -3795,7 +3806,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             if (l == 0 && rf) CFD_TRY(halo_exchange(c, L.g, KS, const_cast<double *>(rf->q)));      // r_old's rows are there already
             else if (!rhs_sent[l]) {
                 Geo gb = L.g;
-                if (c32 && l == 1) gb.pitch /= 2;              // float right-hand side of the first coarse level
+                if (own32(l)) gb.pitch /= 2;                   // float right-hand side of a coarse level
                 CFD_TRY(halo_exchange(c, gb, KS, const_cast<double *>(rhs[l])));
             }
             if (l == 0 && rf) {
@@ -3820,7 +3831,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                 else
                     hipLaunchKernelGGL((k_mg_down<true>), grid, dim3(256), 0, st, op, mgeo, c->p_diag, rhs[l], om, om2, cur[l], cg, cb);
                 c->probe_end(1, (c->p_diag.on ? 34.0 : 42.0) - (opm.cif ? 12.0 : 0.0) - (c32 ? 1.0 : 0.0));
-            } else if (c32 && l == 1) {
+            } else if (own32(l) && own32(l + 1)) {
+                LAUNCH_WIDE(wide, (k_mg_down_k<false, 3, false, 4, true, 3>), (k_mg_down_k<false, 3, false, 8, true, 3>), grid, opm, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
+            } else if (own32(l)) {
                 LAUNCH_WIDE(wide, (k_mg_down_k<false, 3, false, 4, true, 2>), (k_mg_down_k<false, 3, false, 8, true, 2>), grid, opm, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g));
             } else if (KS == 3) {
                 LAUNCH_WIDE_F(opm.cif != nullptr, wide, (k_mg_down_k<false, 3>), (k_mg_down_k<false, 3, false, 8>), (k_mg_down_k<false, 3, false, 4, true>), (k_mg_down_k<false, 3, false, 8, true>), grid, opm, mgeo, coarse_df, rhs[l], om3, cur[l], cg, cb, ResidFuse{}, c->nts(L.g) | (c->mg_v32_emul ? 2 : 0));
@@ -3831,8 +3844,8 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             if (l < la && (L.g.cutlo || L.g.cuthi)) {
                 // (a single-precision x: rows of half the bytes, which is a plane of half the pitch to the exchange)
                 Geo gx = L.g, gcb = C.g;
-                if ((l == 0 && opm.cif && KS == 3) || (c32 && l == 1)) gx.pitch /= 2;
-                if (c32 && l == 0) gcb.pitch /= 2;             // float right-hand side of the first coarse level
+                if ((l == 0 && opm.cif && KS == 3) || own32(l)) gx.pitch /= 2;
+                if (own32(l + 1)) gcb.pitch /= 2;              // float right-hand side of the next level
                 HaloSpec sp[2] = {{&gx, KS, cur[l]}, {nullptr, 0, nullptr}};
                 int ns = 1;
                 x_sent[l] = 1;
@@ -3921,7 +3934,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         if (la > 0 && l + 1 == la) e += (size_t)C.joff * C.g.pitch;
         else if (l + 1 < la) {
             Geo ge = C.g;
-            if (c32 && l == 0) ge.pitch /= 2;                  // float iterate of the first coarse level
+            if (own32(l + 1)) ge.pitch /= 2;                   // float iterate of the next level
             CFD_TRY(halo_exchange(c, ge, level_fusable(c, l, L.g, cg) && KS > 2 ? 2 : 1, cur[l + 1]));   // rows (j0 - K) >> 1 ...
         }
         if (level_fusable(c, l, L.g, cg)) {
@@ -3931,7 +3944,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
             const dim3 grid(march_grid(mgeo, wide));
             if (!x_sent[l]) {
                 Geo gx = L.g;
-                if ((l == 0 && opm.cif && KS == 3) || (c32 && l == 1)) gx.pitch /= 2;
+                if ((l == 0 && opm.cif && KS == 3) || own32(l)) gx.pitch /= 2;
                 CFD_TRY(halo_exchange(c, gx, KS, cur[l]));
             }
             if (l == 0) {
@@ -3954,7 +3967,10 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                                        oth[l], c->partials);
                 c->probe_end(7, (c->p_diag.on ? 42.0 : 50.0) - (opm.cif ? 12.0 : 0.0) - ((z_f32 && *z_f32) ? 4.0 : 0.0) - (c32 ? 1.0 : 0.0));
                 *dot_blocks = (int)grid.x;
-            } else if (c32 && l == 1) {
+            } else if (own32(l) && own32(l + 1)) {
+                LAUNCH_WIDE(wide, (k_mg_up_k<false, 3, 4, true, false, 3>), (k_mg_up_k<false, 3, 8, true, false, 3>), grid, opm, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
+                            oth[l], c->partials, c->nts(L.g));
+            } else if (own32(l)) {
                 LAUNCH_WIDE(wide, (k_mg_up_k<false, 3, 4, true, false, 2>), (k_mg_up_k<false, 3, 8, true, false, 2>), grid, opm, mgeo, coarse_df, rhs[l], cur[l], cg, e, c->mg_gamma, om3,
                             oth[l], c->partials, c->nts(L.g));
             } else if (KS == 3) {

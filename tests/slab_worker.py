@@ -33,6 +33,7 @@ def build_case(name, work):
         "channel_lam_64x128": (lambda: cases.channel_forced(n=64, steps=2, ratio_j=1.0), cases.perturbed_parabola, {"count_j": 128}),
         # large enough for two fused multigrid levels above the tail: the first coarse level keeps single-precision vectors
         "channel_lam_256x256": (lambda: cases.channel_forced(n=256, steps=2, ratio_j=1.0), cases.perturbed_parabola, {}),
+        "channel_lam_512x512": (lambda: cases.channel_forced(n=512, steps=2, ratio_j=1.0), cases.perturbed_parabola, {}),
         "channel_lam_64x256": (lambda: cases.channel_forced(n=64, steps=2, ratio_j=1.0), cases.perturbed_parabola, {"count_j": 256}),
         "inlet_outlet_40x32": (lambda: cases.inlet_outlet_channel(ni=40, nj=32, steps=4), None, {}),
         "couette_piso_24x32": (lambda: cases.couette_piso(ni=24, nj=32, steps=4), cases.perturbed_rest, {}),
@@ -56,8 +57,9 @@ def build_case(name, work):
     cfg["solver"]["turbulence_solver"] = {"tol": 1e-13, "maxiter": 2000}
     # small test meshes: keep the multigrid levels slab-distributed as long as possible
     cfg["solver"]["slab"] = {"min_rows": int(os.environ.get("SLAB_MIN_ROWS", "16"))}
-    if name == "channel_lam_256x256":
-        cfg["solver"]["tuning"] = {"mg_c32_min_cells": 1024}       # (default: first coarse levels of >= 2^18 cells)
+    if name in ("channel_lam_256x256", "channel_lam_512x512"):
+        # (default: coarse levels of more than 2^18 cells; here the 128^2 level, not the 64^2 one a single rank's tail takes)
+        cfg["solver"]["tuning"] = {"mg_c32_min_cells": 4096}
     if os.environ.get("SLAB_UNFUSED"):
         cfg["solver"]["multigrid"] = {"fused": False}
     return cfg

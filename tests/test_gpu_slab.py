@@ -167,7 +167,8 @@ def test_slab_mesh_from_rect(world, tmp_path):
 
 @pytest.mark.parametrize("case,world", [("channel_lam_64x128", 2), ("channel_komega_48x64", 2), ("channel_komega_48x64", 4),
                                         # two fused levels above the tail, the first coarse one with float vectors (mg_c32)
-                                        ("channel_lam_256x256", 2), ("channel_lam_256x256", 4)])
+                                        ("channel_lam_256x256", 2), ("channel_lam_256x256", 4),
+                                        ("channel_lam_512x512", 2)])       # ... the first two coarse levels
 def test_fused_kernels_across_cuts(case, world, tmp_path):
     """The fused kernels read up to four halo rows of the neighbour slab: one V(3,3) cycle on a random
     right-hand side agrees with the single-rank cycle to rounding, and one SIMPLE iteration takes the same
