@@ -196,7 +196,8 @@ __device__ __forceinline__ void store_stream_f32(float *p, float v, int nt) {
 // kernel families counted by Ctx::kc (cfd_kernel_counts): which production kernels a run actually took
 enum {
     KC_CHEB4_2RHS = 0, KC_CHEB4_1RHS, KC_CHEB2, KC_CHEB1, KC_BICGSTAB_IT, KC_FLUX_MARCH, KC_FLUX_MARCH_MULTISTRIP,
-    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_SPEC_ITERS, KC_SPEC_REDONE, KC_PCG_TAIL, KC_CHEB_TAIL, KC_COUNT = 20
+    KC_FLUX_TILE, KC_MG_FUSED_LEVELS_MAX, KC_MG_DEFERRED_RESID, KC_CG_PQ, KC_VCYCLE, KC_MG_LINE_LEVELS_MAX, KC_MG_TAIL_LEVELS, KC_CORRECT_FLUX, KC_MG_SEMI_LEVELS, KC_SPEC_ITERS, KC_SPEC_REDONE, KC_PCG_TAIL, KC_CHEB_TAIL,
+    KC_CHEB6_1RHS, KC_MG_FLOAT_LEVELS_MAX, KC_MESH_FORM, KC_PCG_XSUM, KC_COUNT = 24
 };
 
 // ------------------------------------------------------------------ multigrid level

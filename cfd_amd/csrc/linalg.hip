@@ -2931,6 +2931,7 @@ static int chebyshev_fused(Ctx *c, const OpDev &op, double *const b[2], double *
         // (the first launch of a solve has no x_{k-1})
         c->probe_end(probe_id, 8.0 * (3 + (5 - (m == 1 ? 1 : 0)) * na));
         c->kc[K == 4 ? (na == 2 ? KC_CHEB4_2RHS : KC_CHEB4_1RHS) : KC_CHEB2] += 1;
+        if (six) c->kc[KC_CHEB6_1RHS] += 1;             // (counted among the one-right-hand-side launches as well)
         CFD_HIP(hipGetLastError());
         int k0 = k0m;                              // this launch measured |r_k0| and |r_{k0+Km-1}|
         if (spec) {
@@ -3789,6 +3790,7 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
         }
     }
     const bool c32 = nf32 >= 1;
+    if (nf32 > c->kc[KC_MG_FLOAT_LEVELS_MAX]) c->kc[KC_MG_FLOAT_LEVELS_MAX] = nf32;
     auto own32 = [&](int l) { return l >= 1 && l <= nf32; };        // level l keeps b and x as float
     for (int l = 0; l < n_top; ++l) {
         const Level &L = c->levels[l];
@@ -4583,6 +4585,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     c->p_iters_hint = converged_at > 0 ? converged_at : it;
     if (xsum && it > 0) {
         const XsumArgs xa = ring_args(it);
+        c->kc[KC_PCG_XSUM] += 1;
         if (c->p_ns_active) {
             if (c->pin_i >= 0)
                 hipLaunchKernelGGL(k_ns_shift_sum, dim3(1), dim3(64), 0, st, g, c->pin_i, c->pin_j, c->pin_value, S, (it - 1) & 1, xa, ahist,

@@ -559,7 +559,9 @@ int rect_normals(Ctx *c) {
             bad[0] = 1.0;
         c->rn_state = bad[0] == 0.0 ? (bad[1] == 0.0 ? 2 : 1) : 0;
     }
-    return c->rn_state < c->rn_opt ? c->rn_state : c->rn_opt;
+    const int form = c->rn_state < c->rn_opt ? c->rn_state : c->rn_opt;
+    c->kc[KC_MESH_FORM] = form;           // (a state, not a count: what the flux kernels of this mesh run as)
+    return form;
 }
 
 // lockstep form for the momentum / pressure right-hand-side passes on meshes with enough strips

@@ -466,12 +466,13 @@ class Device:
     KERNEL_COUNT_NAMES = ("cheb4_2rhs", "cheb4_1rhs", "cheb2", "cheb1", "bicgstab_iters", "flux_march",
                           "flux_march_multistrip", "flux_tile", "mg_fused_levels_max", "mg_deferred_resid", "cg_pq",
                           "vcycles", "mg_line_levels_max", "mg_tail_levels", "correct_flux", "mg_semi_levels",
-                          "speculative_iterations", "speculative_redone", "pcg_tail", "cheb_tail")
+                          "speculative_iterations", "speculative_redone", "pcg_tail", "cheb_tail",
+                          "cheb6_1rhs", "mg_float_levels", "mesh_form", "pcg_xsum")
 
     def kernel_counts(self, reset=False):
         """Launches per kernel family since the last reset (include/cfd_hip.h: cfd_kernel_counts)."""
-        out = (C.c_longlong * 20)()
-        check(self.lib.cfd_kernel_counts(self._h, out, 20, int(reset)))
+        out = (C.c_longlong * 24)()
+        check(self.lib.cfd_kernel_counts(self._h, out, 24, int(reset)))
         return dict(zip(self.KERNEL_COUNT_NAMES, [int(v) for v in out]))
 
     def host_counters(self, reset=False):

@@ -453,7 +453,11 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
  * (option "speculate": solves replay the previous iteration's schedule, one host read at the iteration's end, stopping
  * tests evaluated then), [17] of those, iterations whose test failed and that were repeated host-checked, [18] pressure
  * solves that were ONE launch (k_pcg_tail: the whole MG-PCG solve of a mesh whose hierarchy fits one workgroup's LDS),
- * [19] transport solves (momentum, k / omega) that were ONE launch (k_cheb_tail).  n <= 20 entries are written.  No counterpart in the reference.  */
+ * [19] transport solves (momentum, k / omega) that were ONE launch (k_cheb_tail), [20] of the one-right-hand-side Chebyshev
+ * launches, those that fused six iterations (k_chebk<1,6>), [21] max number of coarse multigrid levels that kept their vectors
+ * in single precision, [22] form of the marching flux kernels on this mesh (0 general, 1 axis-aligned: normals from the area
+ * planes, 2 separable areas as well; a state, not a count), [23] pressure solves whose solution was summed from the kept
+ * directions (k_cg_xsum).  n <= 24 entries are written.  No counterpart in the reference.  */
 int cfd_kernel_counts(cfd_ctx *ctx, long long *counts, int n, int reset);
 /* Host-side cost of the calls so far, process wide: out[0] = kernel launches, out[1] = blocking stream
  * synchronisations the library issued (each one idles the GPU while the host reads a scalar).  They bound the step

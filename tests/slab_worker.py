@@ -219,6 +219,8 @@ def main():
         log = np.loadtxt(work / "postproc" / f"{cfg['case_name']}_residual_log.txt", skiprows=1, ndmin=2)
         np.savez(out_dir / "result.npz", step=step, time=time, log=log, correct_flux=hip_solver.LAST_RUN["kernel_counts"]["correct_flux"],
                  spec_iters=hip_solver.LAST_RUN["kernel_counts"]["speculative_iterations"],
+                 float_levels=hip_solver.LAST_RUN["kernel_counts"]["mg_float_levels"],
+                 mesh_form=hip_solver.LAST_RUN["kernel_counts"]["mesh_form"],
                  **{f"field_{k}": v for k, v in fields.items()})
     if world > 1:
         dist.barrier()

@@ -711,6 +711,7 @@ def test_pcg_solution_summed_from_the_kept_directions(n, p_tol, spec):
         dev.close()
     (f1, st1, k1), (f0, st0, k0) = out[1], out[0]
     assert k1["cg_pq"] == k0["cg_pq"] > 0 and st1["p_iters"] == st0["p_iters"]
+    assert k1["pcg_xsum"] > 0 and k0["pcg_xsum"] == 0
     assert (st1["p_iters"] > 6) == (p_tol < 1e-10), st1["p_iters"]
     for a, b in zip(f1, f0):
         assert np.array_equal(mask_corners(a), mask_corners(b)), np.abs(a - b).max()
@@ -749,6 +750,7 @@ def test_axis_aligned_meshes_leave_the_normal_planes_alone(kind):
         f1, n1, b1, k1 = out[rn]
         assert n1 == n0 and b1 == (112.0 if kind == "annulus" else expect), (rn, n1, n0, b1)
         assert k1["flux_march"] == k0["flux_march"] and k1["correct_flux"] == k0["correct_flux"]
+        assert k1["mesh_form"] == (0 if kind == "annulus" else rn) and k0["mesh_form"] == 0
         if kind != "annulus":
             assert k1["correct_flux"] > 0
         for a, b in zip(f1, f0):
@@ -784,6 +786,8 @@ def test_six_fused_chebyshev_iterations_for_a_single_right_hand_side(turbulent, 
     assert k1["cheb4_2rhs"] + k1["cheb4_1rhs"] <= k0["cheb4_2rhs"] + k0["cheb4_1rhs"], (k1, k0)
     if not turbulent:
         assert k1["cheb4_1rhs"] < k0["cheb4_1rhs"], (k1, k0)
+        assert k1["cheb6_1rhs"] > 0
+    assert k0["cheb6_1rhs"] == 0
     assert abs(st1["mom_iters"] - st0["mom_iters"]) <= 2
     assert k1["bicgstab_iters"] == k0["bicgstab_iters"] == 0 and st1["p_iters"] == st0["p_iters"]
     if spec:
@@ -820,6 +824,7 @@ def test_first_coarse_level_in_single_precision():
     for c32 in (1, 2):          # float vectors on the first / the first two coarse levels (512^2: levels 256^2 and 128^2)
         f1, st1, za1, za2, k1 = out[c32]
         assert k1["mg_fused_levels_max"] >= 3 and abs(st1["p_iters"] - st0["p_iters"]) <= 1 and st1["p_relres"] <= 1e-11
+        assert k1["mg_float_levels"] == c32 and k0["mg_float_levels"] == 0
         sym = abs(np.vdot(r1, za2) - np.vdot(za1, r2)) / abs(np.vdot(r1, za2))
         assert np.vdot(r1, za1) > 0.0 and np.vdot(r2, za2) > 0.0 and sym < 1e-5, sym
         # the preconditioners differ at the single-precision level, and only there

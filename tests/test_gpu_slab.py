@@ -85,6 +85,11 @@ def test_slab_run_matches_single_rank(case, world, min_rows, tmp_path):
     # slab contexts replay their solver schedules like a single rank does (one closing read per iteration; the sums the
     # stopping tests look at are all-reduced before that read)
     assert (int(many["spec_iters"]) > 0) == (int(one["spec_iters"]) > 0), (int(one["spec_iters"]), int(many["spec_iters"]))
+    # ... with the same storage of the coarse multigrid vectors and the same form of the flux kernels (the mesh check is
+    # agreed over the ranks)
+    assert int(many["float_levels"]) == int(one["float_levels"]) and int(many["mesh_form"]) == int(one["mesh_form"])
+    if case == "channel_lam_256x256":
+        assert int(many["float_levels"]) == 1 and int(many["mesh_form"]) == 2
 
 
 @pytest.mark.parametrize("mode", ["rccl", "nccl-torch"])
