@@ -278,7 +278,7 @@ def second_leg(args, n, world, local, barrier, torch, dist, strong):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def variant_legs(args, local, budget_s, steps=3, warmup=2):
+def variant_legs(args, local, budget_s, steps=5, warmup=8):
     """Outside the timed region, single GPU: ms per outer step of the OTHER workloads of the same size -- the wall-graded
     channel and the half annulus (stretched meshes: the reference's own cases are all wall-graded; pressure solve through
     the semi-coarsened line multigrid) and the k-omega channel -- so that the driver's line carries them.  Bounded: a
