@@ -683,6 +683,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "mg_c32") c->mg_c32 = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "mg_c32_min_cells") c->mg_c32_min_cells = iv < 0 ? 0 : iv;
     else if (n == "cheb_k6") c->cheb_k6 = iv ? 1 : 0;
+    else if (n == "fold_sums") c->fold_sums = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "wide_mask") { if (iv < 0 || iv > 1023) { set_error("wide_mask: 0 .. 1023"); return CFD_E_ARG; } c->wide_mask = iv; }

@@ -402,6 +402,7 @@ struct Ctx {
     bool mesh_halo2 = false;           // metric planes hold the neighbour slab's rows beyond the cuts (launch_correct_flux)
     long mg_c32_min_cells = 1L << 18;  // ... from this many cells of the global level on
     int mg_c32 = 2;                    // fused V-cycle: this many coarse levels (0 .. 2, from the first) keep b and x in single precision (vcycle_impl: nf32)
+    int fold_sums = -1;                // fused MG-PCG on one rank: (r, z) and (p, q) summed inside the kernels that consume them (-1: meshes of <= 4M cells)
     int cheb_k6 = 1;                   // Chebyshev launches with one right-hand side left fuse six iterations (single rank, lockstep form)
     int rn_opt = 2, rn_state = -1;     // axis-aligned mesh (stencil.hip: rect_normals): option (cap); -1 not looked at yet / 0 / 1 / 2
     int pcg_xsum = 1;                  // fused MG-PCG: x summed from the kept directions when the solve ends (k_cg_xsum) instead of updated every step

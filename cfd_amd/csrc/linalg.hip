@@ -64,6 +64,21 @@ __global__ void k_sum_finish(const double *partials, int n, int nq, double *out)
     if (tid < nq) out[tid] = (sm[tid][0] + sm[tid][1]) + (sm[tid][2] + sm[tid][3]);
 }
 
+// The same sum inside the kernel that consumes it (option fold_sums, one rank): the first 256 threads of the workgroup
+// add the n partials in k_sum_finish's order -- strided run, wave shuffles, the four wave sums: the same bits -- and
+// every thread gets the result.  One barrier; every thread of the workgroup must call it.  Saves the dependent
+// single-workgroup launch between producer and consumer (two per PCG iteration).
+__device__ __forceinline__ double fold_sum(const double *partials, int n, int tid, double *sm4) {
+    if (tid < 256) {
+        double v = 0.0;
+        for (int t = tid; t < n; t += 256) v += partials[t];
+        v = wsum(v);
+        if ((tid & 63) == 0) sm4[tid >> 6] = v;
+    }
+    __syncthreads();
+    return (sm4[0] + sm4[1]) + (sm4[2] + sm4[3]);
+}
+
 // partials -> out[0..nq), then summed over the slabs of a multi-rank run
 int sum_finish(Ctx *c, const double *partials, int nblocks, int nq, double *out) {
     if (nq < 1 || nq > 8) { set_error("internal: sum_finish of %d sums", nq); return CFD_E_ARG; }
@@ -1728,6 +1743,9 @@ struct ResidFuse {
     double *rnew;
     double *rr_partials = nullptr;     // non-null: |r|^2 of the rows a block owns, one partial sum per block
     int rr_slot = 0;                   // ... and the Ctx::scal slot their sum goes to (host side)
+    const double *pq_part = nullptr;   // fold_sums: (p, q) still waits as pq_n partial sums; the kernel adds them up itself
+    int pq_n = 0;                      // (fold_sum) and its first workgroup stores the sum to pq_out
+    double *pq_out = nullptr;
 };
 
 // VT (vector types of the first coarse levels, option mg_c32), two bits: 1 the NEXT level keeps its vectors in single
@@ -1775,7 +1793,18 @@ template <bool FINE, int K, bool RF = false, int WPB = 4, bool F32 = false, int 
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_mg_down_k(OpDev op, MarchGeo mg, DiagFix df, const double *b, SweepOm<K> om, double *x,
                                                         Geo gc, double *bc, ResidFuse rf = ResidFuse{}, int nts = 0) {
     const Geo g = op.g;
-    const double alpha = RF ? safe_div(rf.rz[0], rf.pq[0]) : 0.0;
+    double alpha = 0.0;
+    if (RF) {
+        double pq;
+        if (rf.pq_n > 0) {
+            __shared__ double fsm[4];
+            pq = fold_sum(rf.pq_part, rf.pq_n, threadIdx.x, fsm);
+            if (blockIdx.x == 0 && threadIdx.x == 0) rf.pq_out[0] = pq;
+        } else {
+            pq = rf.pq[0];
+        }
+        alpha = safe_div(rf.rz[0], pq);
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const size_t P = g.pitch;
     constexpr int W = 64 - 2 * K;
@@ -4103,14 +4132,24 @@ __global__ void k_cg_init(Geo g, Tiling T, const double *b, double *r, double *x
 // five planes and writes one instead of reading and writing x in every step (-16 B per cell and step from the third).
 // `alpha_out` (NOX, not the first step) receives alpha_prev.
 template <int WPB, bool FIRST, bool XZERO, bool ZF = false, bool NOX = false>
-__global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, const CgScal *s, int gen,
+__global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagFix df, CgScal *s, int gen,
                                                     const double *z, const double *pold, double *pnew, double *q, double *x, double *partials,
-                                                    int nts, double *alpha_out) {
+                                                    int nts, double *alpha_out, const double *rz_part, int rz_n) {
     const Geo g = op.g;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: row loops and addresses stay scalar
     const size_t P = g.pitch;
     constexpr bool first = FIRST, xzero = XZERO || NOX;
-    const double beta = first ? 0.0 : safe_div(s->rz[gen], s->rz[gen ^ 1]);
+    // fold_sums: (r, z) of this iteration still waits as rz_n partial sums of the V-cycle's last pass (fold_sum); the first
+    // workgroup stores it where the later kernels of the iteration read it
+    double rz_cur;
+    if (rz_n > 0) {
+        __shared__ double fsm[4];
+        rz_cur = fold_sum(rz_part, rz_n, threadIdx.x, fsm);
+        if (blockIdx.x == 0 && threadIdx.x == 0) s->rz[gen] = rz_cur;
+    } else {
+        rz_cur = s->rz[gen];
+    }
+    const double beta = first ? 0.0 : safe_div(rz_cur, s->rz[gen ^ 1]);
     const double alpha_prev = first ? 0.0 : safe_div(s->rz[gen ^ 1], s->pq);
     if (NOX && !first && blockIdx.x == 0 && threadIdx.x == 0) alpha_out[0] = alpha_prev;
     double dot = 0.0;
@@ -4208,8 +4247,17 @@ __global__ __launch_bounds__(64 * WPB) void k_cg_pq(OpDev op, MarchGeo mg, DiagF
     }
 }
 // r -= alpha q ; partial = (r, r)
-__global__ void k_cg_r(Geo g, Tiling T, const CgScal *s, int gen, const double *q, double *r, double *partials, int nts) {
-    const double alpha = safe_div(s->rz[gen], s->pq);
+__global__ void k_cg_r(Geo g, Tiling T, CgScal *s, int gen, const double *q, double *r, double *partials, int nts,
+                       const double *pq_part = nullptr, int pq_n = 0) {
+    double pq;
+    if (pq_n > 0) {          // fold_sums: (p, q) summed here (see k_cg_pq)
+        __shared__ double fsm[4];
+        pq = fold_sum(pq_part, pq_n, (int)(threadIdx.y * blockDim.x + threadIdx.x), fsm);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) s->pq = pq;
+    } else {
+        pq = s->pq;
+    }
+    const double alpha = safe_div(s->rz[gen], pq);
     double acc[1] = {0.0};
     TILE_LOOP(g, T) {
         const size_t c = g.cell(i, j);
@@ -4361,6 +4409,14 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     // test entry points hand in kry[11] / kry[12] as b and x: whatever the caller uses is left out; kry[10] keeps the saved
     // right-hand side of the nearly-symmetric regime)
     const bool xsum = fused && c->pcg_xsum;
+    // fold_sums (one rank): (r, z) and (p, q) are added up by the kernel that consumes them (fold_sum) instead of by a
+    // single-workgroup launch in between; (p, q) partial sums then go to a buffer of their own, because the direction step
+    // writes them while its other workgroups still read the (r, z) ones
+    // (auto: meshes of up to 4M cells, where a dependent launch costs a visible share of the step -- 2 - 3 % of it at
+    // 64^2 .. 1024^2; at 8192^2 the sum at the head of a thousand workgroups costs as much as the launch it replaces)
+    const bool fold = fused && c->comm.nranks == 1 && (c->fold_sums > 0 || (c->fold_sums < 0 && (long)g.ni * g.nj <= (1L << 22)));
+    double *pq_part = fold ? c->partials + (size_t)5 * MAX_PARTIALS : c->partials;
+    int pq_pending = 0;                // (p, q) of the last direction step still waits as this many partial sums
     double *pring[CG_RING];
     {
         const int cand[9] = {2, 6, 7, 8, 9, 11, 12, 13, 14};
@@ -4448,13 +4504,17 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         if (deferred) {
             ResidFuse rf{q, &S->rz[deferred_gen], &S->pq, r_other};
             if (deferred_rr_slot) { rf.rr_partials = c->partials + (size_t)7 * MAX_PARTIALS; rf.rr_slot = deferred_rr_slot; }
+            if (pq_pending > 0) { rf.pq_part = pq_part; rf.pq_n = pq_pending; rf.pq_out = &S->pq; pq_pending = 0; }
             CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db, &rf, fused ? &zf : nullptr));
             std::swap(r, r_other);
             deferred = false;
         } else {
             CFD_TRY(vcycle_impl(c, r, za, zb, &z, &db, nullptr, fused ? &zf : nullptr));
         }
-        if (db > 0) {
+        int rz_pending = 0;
+        if (db > 0 && fold) {
+            rz_pending = db;                                      // the direction step adds them up itself
+        } else if (db > 0) {
             CFD_TRY(finish_to(c, db, 1, CG_OFF_OF(rz[gen])));     // (r, z) came out of the fused up-sweep
         } else {
             CVecs<1> a1{{r}}, a2{{z}};
@@ -4487,10 +4547,10 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         double *aout = ahist + (it + CG_RING - 1) % CG_RING;                                                                  \
         if (wide == 8)                                                                                                        \
             hipLaunchKernelGGL((k_cg_pq<8, FIRST, XZERO, ZF, NOX>), mgrid, dim3(512), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
-                               c->partials, c->nts(g), aout);                                                                 \
+                               pq_part, c->nts(g), aout, (const double *)c->partials, rz_pending);                            \
         else                                                                                                                  \
             hipLaunchKernelGGL((k_cg_pq<4, FIRST, XZERO, ZF, NOX>), mgrid, dim3(256), 0, st, op, mgeo, c->p_diag, S, gen, z, pold, p, q, x, \
-                               c->partials, c->nts(g), aout);                                                                 \
+                               pq_part, c->nts(g), aout, (const double *)c->partials, rz_pending);                            \
     } while (0)
             if (xsum) {
                 if (zf) {
@@ -4515,7 +4575,8 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             c->probe_end(0, (xsum ? (it == 0 ? 40.0 : 48.0) : (it == 0 ? 40.0 : (it == 1 ? 56.0 : 64.0))) - (zf ? 4.0 : 0.0));
             c->kc[KC_CG_PQ] += 1;
             CFD_HIP(hipGetLastError());
-            CFD_TRY(finish_to(c, (int)mgrid.x, 1, CG_OFF_OF(pq)));
+            if (fold) pq_pending = (int)mgrid.x;
+            else CFD_TRY(sum_finish(c, pq_part, (int)mgrid.x, 1, c->scal + CG_OFF_OF(pq)));
             // (lagged host reads look at |r| of the expected last iteration and the one before it only)
             if (can_defer && it + (c->host_lag ? 2 : 3) < c->p_iters_hint && it + 1 < maxiter) {
                 deferred = true;               // the next V-cycle forms r itself; nobody reads |r| of this iteration
@@ -4534,7 +4595,8 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
                 continue;
             }
             c->probe_begin(11);
-            hipLaunchKernelGGL(k_cg_r, grid, blk, 0, st, g, T, S, gen, q, r, c->partials, c->nts(g));
+            hipLaunchKernelGGL(k_cg_r, grid, blk, 0, st, g, T, S, gen, q, r, c->partials, c->nts(g), (const double *)pq_part, pq_pending);
+            pq_pending = 0;
             c->probe_end(11, 24.0);
         } else {
             hipLaunchKernelGGL(k_cg_p, grid, blk, 0, st, g, T, S, gen, it == 0, z, p);
@@ -4583,6 +4645,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
         if (sqrt(rr) <= tol * sqrt(bb)) break;
     }
     c->p_iters_hint = converged_at > 0 ? converged_at : it;
+    if (pq_pending > 0) CFD_TRY(sum_finish(c, pq_part, pq_pending, 1, c->scal + CG_OFF_OF(pq)));      // (every exit of the loop has consumed it)
     if (xsum && it > 0) {
         const XsumArgs xa = ring_args(it);
         c->kc[KC_PCG_XSUM] += 1;

@@ -835,6 +835,36 @@ def test_first_coarse_level_in_single_precision():
     assert np.abs(out[2][2] - out[1][2]).max() > 0.0       # the second level's rounding is there as well
 
 
+@pytest.mark.parametrize("n,turbulent,graded,spec", [(64, False, False, 1), (256, False, False, 0), (192, True, False, 1), (256, False, True, 1)])
+def test_inner_products_summed_by_the_consuming_kernels(n, turbulent, graded, spec):
+    """Option `fold_sums` (default on, one rank): (r, z) and (p, q) of the fused MG-PCG are added up inside the kernel that
+    consumes them (direction step; residual update) in the order of the single-workgroup finish kernel they replace -- the
+    same bits, two dependent launches per PCG iteration fewer.  Uniform, k-omega and stretched (semi-coarsened) meshes,
+    host-checked and replayed schedules."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for fold in (1, 0):
+        dev, ctl, cfg = bench.setup_device(n, turbulent, 2, 1e-8, 0, tuning={"fold_sums": fold, "speculate": spec}, graded=graded)
+        for step in range(2):
+            advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        launches0, _ = dev.host_counters()
+        for step in range(2, 5):
+            advance_one_step(dev, ctl, step)
+        dev.synchronize()
+        launches1, _ = dev.host_counters()
+        names = (L.F_U, L.F_V, L.F_P, L.F_PCORR) + ((L.F_K, L.F_OMEGA) if turbulent else ())
+        out[fold] = ([dev.download(f) for f in names], dev.stats(), dev.kernel_counts(), launches1 - launches0)
+        dev.close()
+    (f1, st1, k1, l1), (f0, st0, k0, l0) = out[1], out[0]
+    assert k1["cg_pq"] == k0["cg_pq"] > 0 and st1["p_iters"] == st0["p_iters"]
+    assert l1 < l0 and l0 - l1 >= k1["cg_pq"] // 2, (l1, l0, k1["cg_pq"])
+    for a, b in zip(f1, f0):
+        assert np.array_equal(mask_corners(a), mask_corners(b)), np.abs(a - b).max()
+
+
 def _pcg_tail_pair(builder, fixup, tmp_path, extra=None):
     """The same case with the pressure solve as one launch (k_pcg_tail, default on small meshes) and as the launch-per-phase loop."""
     from cfd_amd import mesh as hip_mesh
