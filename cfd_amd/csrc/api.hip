@@ -503,6 +503,7 @@ int cfd_upload_mesh(cfd_ctx *ctx, const double *cell_volume, const double *w_rig
     c->mesh_set = true;
     c->mesh_halo2 = false;
     c->rn_state = -1;
+    c->dtdiff_valid = false;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -528,6 +529,7 @@ int cfd_mesh_from_nodes(cfd_ctx *ctx, const double *node) {
     c->mesh_set = true;
     c->mesh_halo2 = false;
     c->rn_state = -1;
+    c->dtdiff_valid = false;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -554,6 +556,7 @@ int cfd_mesh_from_rect(cfd_ctx *ctx, const double *x_nodes, const double *y_node
     c->mesh_set = true;
     c->mesh_halo2 = false;
     c->rn_state = -1;
+    c->dtdiff_valid = false;
     c->p_built = false;
     c->ap_cached = false;
     return CFD_OK;
@@ -683,6 +686,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "mg_c32") c->mg_c32 = iv < 0 ? 0 : (iv > 2 ? 2 : iv);
     else if (n == "mg_c32_min_cells") c->mg_c32_min_cells = iv < 0 ? 0 : iv;
     else if (n == "cheb_k6") c->cheb_k6 = iv ? 1 : 0;
+    else if (n == "lmin_const") { c->lmin_const = iv ? 1 : 0; c->dtdiff_valid = false; }
     else if (n == "fold_sums") c->fold_sums = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "p_sym_tol") { if (!(value >= 0.0 && value <= 1.0e-2)) { set_error("p_sym_tol: 0 .. 1e-2"); return CFD_E_ARG; } c->p_sym_tol = value; c->p_built = false; }
     else if (n == "cf_form") c->cf_form = iv < 0 ? 0 : (iv > 2 ? 2 : iv);

@@ -402,6 +402,10 @@ struct Ctx {
     bool mesh_halo2 = false;           // metric planes hold the neighbour slab's rows beyond the cuts (launch_correct_flux)
     long mg_c32_min_cells = 1L << 18;  // ... from this many cells of the global level on
     int mg_c32 = 2;                    // fused V-cycle: this many coarse levels (0 .. 2, from the first) keep b and x in single precision (vcycle_impl: nf32)
+    // diffusive time-step minimum of a laminar run, kept once the host has read it (stencil.hip: dt_diff_known)
+    int lmin_const = 1;
+    bool dtdiff_valid = false, dt_pass_diff_fresh = false;
+    double dtdiff_cfl = 0.0, dtdiff_nu = 0.0, dtdiff_val = 0.0;
     int fold_sums = -1;                // fused MG-PCG on one rank: (r, z) and (p, q) summed inside the kernels that consume them (-1: meshes of <= 4M cells)
     int cheb_k6 = 1;                   // Chebyshev launches with one right-hand side left fuse six iterations (single rank, lockstep form)
     int rn_opt = 2, rn_state = -1;     // axis-aligned mesh (stencil.hip: rect_normals): option (cap); -1 not looked at yet / 0 / 1 / 2

@@ -469,7 +469,9 @@ __global__ void k_dt(Geo g, MeshDev m, const double *u, const double *v, const d
     }
 }
 
-__global__ void k_min_finish(const double *partials, int n, int nq, double *out) {      // nq <= 8; shape of k_sum_finish
+// has_fixed1: out[1] is not a minimum of partials but the value the caller knows already (the diffusive time-step minimum
+// of a laminar run, a constant of mesh, nu and cfl_diff: launch_correct_flux)
+__global__ void k_min_finish(const double *partials, int n, int nq, double *out, double fixed1 = 0.0, int has_fixed1 = 0) {      // nq <= 8; shape of k_sum_finish
     __shared__ double sm[8][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = 0; q < nq; ++q) {
@@ -479,7 +481,19 @@ __global__ void k_min_finish(const double *partials, int n, int nq, double *out)
         if (lane == 0) sm[q][wave] = v;
     }
     __syncthreads();
-    if (tid < nq) out[tid] = fmin(fmin(sm[tid][0], sm[tid][1]), fmin(sm[tid][2], sm[tid][3]));
+    if (tid < nq) out[tid] = (has_fixed1 && tid == 1) ? fixed1 : fmin(fmin(sm[tid][0], sm[tid][1]), fmin(sm[tid][2], sm[tid][3]));
+}
+
+// The diffusive minimum min(cfl_diff l^2 / nu) of a laminar run does not change while mesh, nu and cfl_diff stay: the
+// first look-ahead pass computes it (and finish_continuity / launch_dt keep what the host then reads), the later ones
+// leave the l plane alone (8 B per cell) and k_min_finish puts the kept value in its slot -- the same double.
+static inline bool dt_diff_known(const Ctx *c) {
+    return c->lmin_const && c->dtdiff_valid && !c->turbulent && c->dtdiff_cfl == c->dtp_cfl_diff && c->dtdiff_nu == c->nu;
+}
+static inline void dt_diff_keep(Ctx *c, double value) {
+    if (!c->dt_pass_diff_fresh) return;
+    c->dt_pass_diff_fresh = false;
+    c->dtdiff_valid = true; c->dtdiff_cfl = c->dtp_cfl_diff; c->dtdiff_nu = c->nu; c->dtdiff_val = value;
 }
 
 static inline int tiles_of(const Geo &g, int &tx) {
@@ -1279,6 +1293,7 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
             // already on the host (read together with the continuity residual of the pass that computed them)
             c->dt_host_valid = false;
             out[0] = c->h_dt_ahead[0]; out[1] = c->h_dt_ahead[1];
+            if (use_cfl_diff) dt_diff_keep(c, out[1]);
             return CFD_OK;
         }
         if (c->dt_host_valid) {
@@ -1290,8 +1305,11 @@ int launch_dt(Ctx *c, int use_cfl, double cfl, int use_cfl_diff, double cfl_diff
             return CFD_OK;
         }
         CFD_TRY(all_reduce(c, c->scal + DT_AHEAD_OFF, 2, 1));
-        return read_scalars(c, DT_AHEAD_OFF, 2, out);
+        CFD_TRY(read_scalars(c, DT_AHEAD_OFF, 2, out));
+        if (use_cfl_diff && c->dt_ahead_diff) dt_diff_keep(c, out[1]);
+        return CFD_OK;
     }
+    c->dt_pass_diff_fresh = false;
     int nb;
     if (c->march_flux) {
         // marching form: every row of u, v and of the metric planes is read once (88 instead of ~117 B/cell)
@@ -1404,10 +1422,12 @@ int launch_correct_flux(Ctx *c, double dt, double ru, double rv, double rp, bool
     // u*, v*, u0, v0, p0, p', a_P, V, w x 2, n x 4, S x 2 read; u, v, p, b_u, b_v written (+ k, + lmin)
     // (axis-aligned mesh: the four normal planes are not read)
     const int rn = rect_normals(c);
-    c->last_rhs_bytes = 176.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0) - (rn == 2 ? 16.0 : 0.0);
+    const bool diff_known = dt_too && c->dtp_use_diff && dt_diff_known(c);
+    c->last_rhs_bytes = 176.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff && !diff_known) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0) - (rn == 2 ? 16.0 : 0.0);
     if (dt_too) {
         ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
-        ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
+        ma.use_diff = (c->turbulent || diff_known) ? 0 : c->dtp_use_diff;
+        c->dt_pass_diff_fresh = ma.use_diff != 0;
 #define LAUNCH_CF(KGv, DTv)                                                                                                   \
     do {                                                                                                                     \
         if (rn == 2) {                                                                                                       \
@@ -1422,7 +1442,7 @@ int launch_correct_flux(Ctx *c, double dt, double ru, double rv, double rp, bool
         if (c->turbulent) LAUNCH_CF(true, true);
         else LAUNCH_CF(false, true);
         hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials + MAX_PARTIALS, fm.blocks, 2,
-                           c->scal + DT_AHEAD_OFF);
+                           c->scal + DT_AHEAD_OFF, diff_known ? c->dtdiff_val : 0.0, diff_known ? 1 : 0);
     } else if (c->turbulent) {
         LAUNCH_CF(true, false);
     } else {
@@ -1506,7 +1526,8 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         // 13 planes read (u, v, p, a_P, V, w x 2, n x 4, S x 2), b_u, b_v written; + k in turbulent runs; + lmin for the
         // diffusive minimum taken ahead
         const int rn = rect_normals(c);
-        c->last_rhs_bytes = 120.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0) - (rn == 2 ? 16.0 : 0.0);
+        const bool diff_known = dt_too && c->dtp_use_diff && dt_diff_known(c);
+        c->last_rhs_bytes = 120.0 + (c->turbulent ? 8.0 : 0.0) + ((dt_too && !c->turbulent && c->dtp_use_diff && !diff_known) ? 8.0 : 0.0) - (rn ? 32.0 : 0.0) - (rn == 2 ? 16.0 : 0.0);
 #define LAUNCH_FM2(KGv, DTv)                                                                                                  \
     do {                                                                                                                     \
         if (rn == 2) LAUNCH_FLUX(fm, (k_flux_march<2, KGv, DTv, 4, 2>), (k_flux_march<2, KGv, DTv, 8, 2>), c->g, c->mesh(), f, fm, ma, (double *)nullptr, c->partials); \
@@ -1516,11 +1537,12 @@ int launch_momentum_rhs(Ctx *c, double dt, const double *u, const double *v, con
         if (dt_too) {
             // turbulent runs: nu_t changes before the next step, only the advective minimum can be taken ahead
             ma.nu = c->nu; ma.cfl = c->dtp_cfl; ma.cfl_diff = c->dtp_cfl_diff; ma.use_cfl = c->dtp_use_cfl;
-            ma.use_diff = c->turbulent ? 0 : c->dtp_use_diff;
+            ma.use_diff = (c->turbulent || diff_known) ? 0 : c->dtp_use_diff;
+            c->dt_pass_diff_fresh = ma.use_diff != 0;
             if (c->turbulent) LAUNCH_FM2(true, true);
             else LAUNCH_FM2(false, true);
             hipLaunchKernelGGL(k_min_finish, dim3(1), dim3(256), 0, c->stream, c->partials + MAX_PARTIALS, fm.blocks, 2,
-                               c->scal + DT_AHEAD_OFF);
+                               c->scal + DT_AHEAD_OFF, diff_known ? c->dtdiff_val : 0.0, diff_known ? 1 : 0);
             c->dt_ahead = true;
             c->dt_ahead_diff = !c->turbulent;
             c->dt_ahead_cur = c->cur;

@@ -757,6 +757,39 @@ def test_axis_aligned_meshes_leave_the_normal_planes_alone(kind):
             assert np.array_equal(mask_corners(a), mask_corners(b)), (rn, np.abs(a - b).max())
 
 
+def test_laminar_diffusive_time_step_minimum_is_kept():
+    """In a laminar run min(cfl_diff l^2 / nu) is a constant of mesh, nu and cfl_diff: the first look-ahead pass of
+    k_correct_flux computes it, the host reads it with the continuity residual, and the later passes leave the l plane
+    alone (8 B per cell; option `lmin_const`, default on) while k_min_finish puts the kept double in its slot.  Time
+    steps and fields are the ones the option off gives, bit for bit, also across a change of cfl_diff (new key: one
+    fresh pass)."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for lc in (1, 0):
+        dev, ctl, cfg = bench.setup_device(192, False, 2, 1e-8, 0, tuning={"lmin_const": lc}, graded=True)
+        dev.probe(2)
+        dts = []
+        for step in range(6):
+            if step == 3:
+                ctl.cfl_diff = 0.5 * ctl.cfl_diff
+            r = advance_one_step(dev, ctl, step)
+            dts.append((r["dt"], r["dt_adv"], r["dt_diff"]))
+        dev.synchronize()
+        n, _, bpc = dev.probe_read(with_bytes=True)
+        dev.probe(-1)
+        out[lc] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P)], dts, n, bpc)
+        dev.close()
+    f1, d1, n1, b1 = out[1]
+    f0, d0, n0, b0 = out[0]
+    assert d1 == d0, (d1, d0)
+    assert d0[3][2] == 0.5 * d0[2][2]
+    assert n1 == n0 and b0 - 8.0 < b1 < b0, (n1, n0, b1, b0)     # mean bytes per cell over the probed launches
+    for a, b in zip(f1, f0):
+        assert np.array_equal(mask_corners(a), mask_corners(b)), np.abs(a - b).max()
+
+
 @pytest.mark.parametrize("turbulent,spec", [(False, 1), (False, 0), (True, 1)])
 def test_six_fused_chebyshev_iterations_for_a_single_right_hand_side(turbulent, spec):
     """Option `cheb_k6` (default on, single rank, lockstep form: meshes of >= 832 columns): once one of the two right-hand
