@@ -657,6 +657,7 @@ int cfd_set_option(cfd_ctx *ctx, const char *name, double value) {
     else if (n == "fuse_nut") c->fuse_nut = iv ? 1 : 0;
     else if (n == "dt_lookahead") c->dt_lookahead = iv ? 1 : 0;
     else if (n == "fuse_resid") c->fuse_resid = iv ? 1 : 0;
+    else if (n == "semi_resid") c->semi_resid = iv ? 1 : 0;
     else if (n == "nt_stores") c->nt_stores = iv < 0 ? -1 : (iv ? 1 : 0);
     else if (n == "march_ls") { if (iv < 0 || iv > 1024) { set_error("march_ls: 0 .. 1024"); return CFD_E_ARG; } c->march_ls = iv; }
     else if (n == "march_ls_model") c->march_ls_model = iv ? 1 : 0;

@@ -458,6 +458,7 @@ struct Ctx {
     bool dt_ahead = false, dt_ahead_diff = false, dtp_set = false;
     int dt_ahead_cur = 0, dtp_use_cfl = 0, dtp_use_diff = 0;
     double dtp_cfl = 0.0, dtp_cfl_diff = 0.0;
+    int semi_resid = 1;          // ... and on semi-coarsened hierarchies by the two kernels of the finest level's way down
     int fuse_resid = 1;          // PCG: r = r - alpha q formed by the next V-cycle's pre-smoother on unchecked iterations
     int fuse_nut = 1;            // k-omega: eddy viscosity evaluated inside the conductance pass (k_komega_coeffs)
     int march_flux = 1;          // marching form of the Rhie-Chow flux kernels (momentum / pressure RHS, continuity)

@@ -3765,9 +3765,9 @@ static int vcycle_impl(Ctx *c, const double *r, double *z0, double *z1, double *
                        const ResidFuse *rf = nullptr, bool *z_f32 = nullptr) {
     if (z_f32) *z_f32 = false;
     if (c->semi_on) {
-        if (rf) { set_error("internal: deferred residual update on a semi-coarsened hierarchy"); return CFD_E_STATE; }
+        if (rf && rf->rr_partials) { set_error("internal: (r, r) by-product asked of a semi-coarsened hierarchy"); return CFD_E_STATE; }
         const bool z32 = z_f32 && c->mg_f32 && c->semi_z32;      // the caller takes z as a float plane (the PCG direction step does)
-        CFD_TRY(semi_vcycle(c, r, z0, z1 != z0 ? z1 : nullptr, z32, dot_blocks));
+        CFD_TRY(semi_vcycle(c, r, z0, z1 != z0 ? z1 : nullptr, z32, dot_blocks, rf));
         if (z32) *z_f32 = true;
         *zout = z0;
         return CFD_OK;
@@ -4491,8 +4491,11 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
     // Iterations whose |r| the host does not look at leave r = r - alpha q to the pre-smoother of the next V-cycle
     // (k_mg_down_k<true, 3, true>): r ping-pongs between the right-hand side plane and kry[1].  Needs the three-sweep
     // marching kernels on the finest level; on j-slabs q crosses the cuts in place of r.
-    const bool can_defer = c->fuse_resid && fused && c->levels.size() > 1 && c->mg_pre == 3 && c->mg_post == 3 &&
-                           level_fusable(c, 0, L0.g, coarse_view(c, 1));
+    // (semi-coarsened hierarchies: the two kernels of the finest level's way down form r, option semi_resid; no (r, r)
+    // by-product there)
+    const bool semi_defer = c->semi_on && c->semi_resid && c->fuse_resid && fused;
+    const bool can_defer = semi_defer || (c->fuse_resid && fused && c->levels.size() > 1 && c->mg_pre == 3 && c->mg_post == 3 &&
+                                          level_fusable(c, 0, L0.g, coarse_view(c, 1)));
     double *r_other = c->kry[1];
     bool deferred = false;
     int deferred_gen = 0, deferred_rr_slot = 0;
@@ -4587,7 +4590,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
             }
             // the iteration before the expected last one: its |r|^2 is only read together with the last one's, so the
             // next V-cycle's pre-smoother forms r AND sums (r, r) into the history slot (no k_cg_r pass: 24 B per cell)
-            if (can_defer && c->host_lag && c->rr_byproduct && it + 2 == c->p_iters_hint && it + 1 < maxiter) {
+            if (can_defer && !semi_defer && c->host_lag && c->rr_byproduct && it + 2 == c->p_iters_hint && it + 1 < maxiter) {
                 deferred = true;
                 deferred_gen = gen;
                 deferred_rr_slot = RR_HIST_OFF + ((it + 1) & 7);

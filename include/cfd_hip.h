@@ -440,7 +440,7 @@ int cfd_probe_read_id(cfd_ctx *ctx, int kernel, int *count, double *avg_us, doub
  * "pcg_tail" (1 / 0: the pressure solve of a mesh whose hierarchy fits one workgroup's LDS is one launch with the
  * stopping test on the device / the launch-per-phase loop), "pcg_tail_cells" (cell limit of that path), "march_ls_model",
  * "speculate" (-1 / 0 / 1: inner iterations with one host read at their end, see cfd_kernel_counts; auto = contexts of
- * at most 4M cells, j-slab contexts of at most 16M cells), "fuse_correct_slab", "skip_fresh_bc", "probe_capacity" (launches a probe run can time), "mg_v32_emul" (measurement aid), "mg_c32" (0 .. 2: coarse multigrid levels, from the first, with single-precision vectors; levels of more than "mg_c32_min_cells" cells of the global level, default 2^18), "rect_normals" (1 / 0: axis-aligned meshes do not read the normal planes), "cheb_k6" (1 / 0: six fused Chebyshev iterations for a single right-hand side where that saves a launch), "fold_sums" (-1 / 0 / 1: PCG inner products summed inside the consuming kernels, auto = one-rank contexts of at most 4M cells), "lmin_const" (1 / 0: in laminar runs the diffusive time-step minimum, a constant of mesh, nu and cfl_diff, is computed by the first look-ahead pass and kept / computed by every pass; same bits), "pcg_xsum" (1 / 0: the pressure solution is summed from the kept PCG directions when the solve ends / updated in every direction step; same bits), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
+ * at most 4M cells, j-slab contexts of at most 16M cells), "fuse_correct_slab", "skip_fresh_bc", "probe_capacity" (launches a probe run can time), "mg_v32_emul" (measurement aid), "mg_c32" (0 .. 2: coarse multigrid levels, from the first, with single-precision vectors; levels of more than "mg_c32_min_cells" cells of the global level, default 2^18), "rect_normals" (1 / 0: axis-aligned meshes do not read the normal planes), "cheb_k6" (1 / 0: six fused Chebyshev iterations for a single right-hand side where that saves a launch), "fold_sums" (-1 / 0 / 1: PCG inner products summed inside the consuming kernels, auto = one-rank contexts of at most 4M cells), "semi_resid" (1 / 0: on semi-coarsened hierarchies the PCG residual update of unchecked iterations is formed by the finest level's way down / by k_cg_r; same bits), "lmin_const" (1 / 0: in laminar runs the diffusive time-step minimum, a constant of mesh, nu and cfl_diff, is computed by the first look-ahead pass and kept / computed by every pass; same bits), "pcg_xsum" (1 / 0: the pressure solution is summed from the kept PCG directions when the solve ends / updated in every direction step; same bits), "rr_byproduct" (1 / 0: (r, r) of the second-to-last expected PCG iteration summed by the
  * next pre-smoothing pass / by its own pass).  INTEGRATION.md section 4 has the table.  No counterpart in the reference.     */
 int cfd_set_option(cfd_ctx *ctx, const char *name, double value);
 /* Launch counts per kernel family since the last reset, so that a parity test can assert WHICH production kernels

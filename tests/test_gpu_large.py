@@ -757,6 +757,39 @@ def test_axis_aligned_meshes_leave_the_normal_planes_alone(kind):
             assert np.array_equal(mask_corners(a), mask_corners(b)), (rn, np.abs(a - b).max())
 
 
+@pytest.mark.parametrize("kind", ["graded", "annulus"])
+def test_residual_update_inside_the_semi_coarsened_way_down(kind):
+    """Stretched meshes (semi-coarsened line multigrid): on the PCG iterations whose |r| nobody reads, r = r - alpha q is
+    formed by the two kernels of the finest level's way down (k_semi_even_down / k_semi_odd_down<.., true>: they read
+    r_old and q where they would read r and store their rows of r) instead of by a k_cg_r pass of its own (option
+    `semi_resid`, default on).  Same expression, same operands: fields, iteration counts and residuals are the ones the
+    separate pass gives, bit for bit."""
+    import bench
+    from cfd_amd import _lib as L
+    from cfd_amd.solver import advance_one_step
+    out = {}
+    for sr in (1, 0):
+        if kind == "annulus":
+            dev, ctl, cfg = bench.setup_annulus(256, 128, 2, 1e-8, 0, tuning={"semi_resid": sr})
+        else:
+            dev, ctl, cfg = bench.setup_device(256, False, 2, 1e-8, 0, tuning={"semi_resid": sr}, graded=True)
+        hist = []
+        for step in range(4):
+            r = advance_one_step(dev, ctl, step)
+            hist.append((r["dt"], r["cont"], r["mom_u"], r["mom_v"], dev.stats()["p_iters"]))
+        dev.synchronize()
+        out[sr] = ([dev.download(f) for f in (L.F_U, L.F_V, L.F_P)], hist, dev.kernel_counts())
+        dev.close()
+    f1, h1, k1 = out[1]
+    f0, h0, k0 = out[0]
+    assert k1["mg_semi_levels"] > 1 and k0["mg_semi_levels"] == k1["mg_semi_levels"]
+    assert k1["mg_deferred_resid"] > 0 and k0["mg_deferred_resid"] == 0, (k1, k0)
+    assert k1["vcycles"] == k0["vcycles"]
+    assert h1 == h0, (h1, h0)
+    for a, b in zip(f1, f0):
+        assert np.array_equal(mask_corners(a), mask_corners(b)), np.abs(a - b).max()
+
+
 def test_laminar_diffusive_time_step_minimum_is_kept():
     """In a laminar run min(cfl_diff l^2 / nu) is a constant of mesh, nu and cfl_diff: the first look-ahead pass of
     k_correct_flux computes it, the host reads it with the continuity residual, and the later passes leave the l plane
