@@ -752,10 +752,16 @@ def main():
             # single precision: 30 + 2 F per cell there, 56 + 2 F on the finest level.
             fac = 12.0 if args.mesh == "graded" else 8.0
             vcycle = (56.0 + 2.0 * fac) + (30.0 + 2.0 * fac) if f32 else 2.0 * (60.0 + 2.0 * fac)
-            per_it = 64.0 + 24.0 + vcycle
-            bytes_per_solve = per_it * mean_p_it + 112.0
+            # Iterations whose |r| nobody reads leave r = r - alpha q to the finest level's way down (option semi_resid):
+            # q read and r written there, 16 B instead of k_cg_r's 24.  The right-hand side pass of an axis-aligned mesh
+            # does not read the normal planes (80 B), of a separable one not the area planes either (64 B).
+            deferred = kcounts.get("mg_deferred_resid", 0) / max(1, kcounts.get("vcycles", 1))
+            krylov = 64.0 + 24.0 - 8.0 * deferred
+            rhs_pass = {0: 112.0, 1: 80.0, 2: 64.0}.get(kcounts.get("mesh_form", 0), 112.0)
+            per_it = krylov + vcycle
+            bytes_per_solve = per_it * mean_p_it + rhs_pass
             mix = {"semi_coarsened_levels": kcounts["mg_semi_levels"], "vcycle_bytes_per_fine_cell": vcycle,
-                   "krylov_bytes_per_iteration": 88.0, "rhs_pass": 112.0}
+                   "krylov_bytes_per_iteration": krylov, "residual_updates_in_the_way_down": deferred, "rhs_pass": rhs_pass}
             note = ("semi-coarsened line multigrid: algorithmic bytes of a zebra line V(1,1) cycle over all levels + direction step "
                     "+ residual update, x iterations + right-hand side; time = device time of the pressure phase over the two steps "
                     "that follow the timed region")
