@@ -1049,6 +1049,7 @@ static int run_iteration(Ctx *c, double *res, const std::function<int()> &body) 
     const long spec_cells = c->comm.nranks > 1 ? Ctx::SPEC_AUTO_CELLS_SLAB : Ctx::SPEC_AUTO_CELLS;
     const bool want = c->speculate > 0 || (c->speculate < 0 && (long)c->g.ni * c->g.nj <= spec_cells);
     const bool spec = want && c->host_lag && c->march_flux && c->freeze_pressure && c->p_built && c->spec_age < Ctx::SPEC_RENEW;
+    c->spec_wanted = want && c->host_lag && c->march_flux && c->freeze_pressure;
     const int cur0 = c->cur;
     c->spec_cheb = Ctx::SpecCheb{};
     c->spec_pcg = Ctx::SpecPcg{};

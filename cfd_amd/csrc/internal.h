@@ -360,6 +360,7 @@ struct Ctx {
     int speculate = -1;                // -1: on for contexts of <= SPEC_AUTO_CELLS cells (j-slabs: SPEC_AUTO_CELLS_SLAB), 0 / 1: off / on
     static constexpr long SPEC_AUTO_CELLS = 1L << 22, SPEC_AUTO_CELLS_SLAB = 1L << 24;     // cells of this context (a slab: its own rows)
     bool spec_on = false;              // inside a speculative iteration
+    bool spec_wanted = false;          // this context runs its inner iterations speculatively where it can (run_iteration)
     int spec_age = 0;                  // speculative iterations since the last host-checked one
     static constexpr int SPEC_RENEW = 48;
     double *h_spec = nullptr;          // pinned host copy of Ctx::scal (256 doubles), filled by the closing read

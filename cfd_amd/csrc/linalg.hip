@@ -4636,7 +4636,7 @@ static int pcg_mg(Ctx *c, const double *b, double *x, double tol, int maxiter, i
                 converged_at = it;
                 if (it == hint0)
                     for (int k = it - 1; k >= 1 && k + 1 >= hint0; --k)
-                        if (sqrt(hist[k & 7]) <= tol * sqrt(bb)) converged_at = k;
+                        if (sqrt(hist[k & 7]) <= (c->spec_wanted ? SPEC_MARGIN : 1.0) * tol * sqrt(bb)) converged_at = k;      // (see spec_verify)
                 break;
             }
             continue;
@@ -4759,7 +4759,12 @@ int spec_verify(Ctx *c, double *res, bool *ok) {
         c->stats.p_relres = bb > 0.0 ? sqrt(rr / bb) : 0.0;
         if (s == sp.n - 1 && sp.hint[s] >= 2) {
             const double r1 = slot[(sp.hint[s] - 1) & 7];
-            if (r1 == r1 && sqrt(r1) <= sp.tol[s] * sqrt(bb)) c->p_iters_hint = sp.hint[s] - 1;
+            // (with a factor to spare, like the Chebyshev schedules: an iterate that meets the test narrowly in one step
+            // misses it in the next, and every miss repeats an inner iteration -- a 2048^2 graded channel alternated
+            // between 11.7 and 18.5 ms per step for twenty steps at a time; 13.7 -> 12.45 ms per step over 300 steps.
+            // Measured and not adopted: the largest count of the last eight solves as the expectation (no repeats, one to
+            // two iterations more on every solve: 13.5 ms), one expectation per inner iteration of a step (12.48 ms))
+            if (r1 == r1 && sqrt(r1) <= SPEC_MARGIN * sp.tol[s] * sqrt(bb)) c->p_iters_hint = sp.hint[s] - 1;
         }
     }
     return CFD_OK;
