@@ -756,7 +756,11 @@ def main():
             # q read and r written there, 16 B instead of k_cg_r's 24.  The right-hand side pass of an axis-aligned mesh
             # does not read the normal planes (80 B), of a separable one not the area planes either (64 B).
             deferred = kcounts.get("mg_deferred_resid", 0) / max(1, kcounts.get("vcycles", 1))
-            krylov = 64.0 + 24.0 - 8.0 * deferred
+            # z goes from the way up to the direction step as a float plane (option semi_z32, default on with mg_f32)
+            z32 = f32 and "semi_z32=0" not in (args.tuning or "")
+            if z32:
+                vcycle -= 4.0
+            krylov = 64.0 - (4.0 if z32 else 0.0) + 24.0 - 8.0 * deferred
             rhs_pass = {0: 112.0, 1: 80.0, 2: 64.0}.get(kcounts.get("mesh_form", 0), 112.0)
             per_it = krylov + vcycle
             bytes_per_solve = per_it * mean_p_it + rhs_pass

@@ -493,9 +493,10 @@ struct Ctx {
     int fused_min = 4;                 // smallest side from which the marching forms of the solvers run (PCG direction step, fused
                                        // Chebyshev, fused correction): periodic wraps need ni >= the kernel's halo lanes (2)
     int tail_from = 0;                 // first multigrid level k_mg_tail may start from (0: a small mesh's whole V-cycle in one launch)
-    int semi_z32 = 0;                  // semi-coarsened cycle: z handed to the PCG direction step in single precision (with mg_f32).  Off:
-                                       // measured on the 8192-wide stretched meshes it saves 4 % per iteration and costs 0.4 - 0.6
-                                       // iterations per solve (graded 105.9 against 104.7 ms per step, annulus 58.5 against 59.1)
+    int semi_z32 = 1;                  // semi-coarsened cycle: z handed to the PCG direction step in single precision (with mg_f32), as the
+                                       // uniform path does.  Off until the end of round 3 (it saved 4 % per iteration and cost 0.4 - 0.6
+                                       // iterations per solve then: 105.9 against 104.7 ms); with the final kernels the 8192-wide graded
+                                       // channel runs 75.9 against 79.7 ms per step, the annulus 49.3 against 51.3, same iteration counts
     int semi_fuse_up = 1;              // semi-coarsened cycle: both colours of the way up in one marching pass on the large levels
     int mg_semi = 1;
     bool semi_on = false;
